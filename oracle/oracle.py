@@ -1,0 +1,344 @@
+"""ctypes binding of the CPU oracle (oracle/qldpc_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (qldpc-branched-off_amd/) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libqldpc_oracle.so")
+
+ALPHA_CONST, ALPHA_DYNAMIC, ALPHA_SEQ = 0, 1, 2
+
+
+def build(force=False):
+    """gcc-compile the oracle (seconds).  Safe to call repeatedly."""
+    src = os.path.join(_HERE, "qldpc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_minsum_decode.restype = C.c_int
+        _lib.orc_minsum_dense_driver.restype = C.c_int
+        _lib.orc_bp_dense_driver.restype = C.c_int
+        _lib.orc_gf2_elimination.restype = C.c_int
+        _lib.orc_gf2_elimination_packed.restype = C.c_int
+        _lib.orc_packed_words.restype = C.c_int
+        _lib.orc_generate_noisy_circuit.restype = C.c_int64
+        _lib.orc_bernoulli_threshold.restype = C.c_uint32
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i8(a):
+    return np.ascontiguousarray(a, dtype=np.int8)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _alpha_args(alpha_mode, alpha):
+    """Mirror of the mode selection in src/decoding/sparse.py:18-29,36-39."""
+    if alpha_mode is None:
+        mode = ALPHA_DYNAMIC if alpha == 0 else ALPHA_CONST
+    elif alpha_mode == "dynamical":
+        mode = ALPHA_DYNAMIC
+    elif alpha_mode == "alvarado":
+        if alpha <= 0:
+            raise ValueError("alpha must be > 0 when alpha_mode='alvarado'")
+        mode = ALPHA_CONST
+    elif alpha_mode == "alvarado-autoregressive":
+        mode = ALPHA_SEQ
+    else:
+        raise ValueError(f"Unsupported alpha_mode: {alpha_mode}")
+    if mode == ALPHA_SEQ:
+        seq = _f64(alpha)
+        if seq.ndim != 1 or seq.size == 0:
+            raise ValueError("alpha must be a non-empty 1D sequence for alvarado-autoregressive")
+        return mode, 0.0, seq
+    return mode, float(alpha), np.zeros(1)
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def minsum_decode_batch(indptr, indices, n, syndromes, prior, max_iter=100, alpha=1.0, alpha_mode="dynamical",
+                        damping=1.0, clip_llr=20.0, threads=1):
+    """Batched a1/a2.  Returns (err int8[B,n], conv uint8[B], llr f64[B,n], iters int32[B])."""
+    indptr, indices = _i32(indptr), _i32(indices)
+    m = indptr.size - 1
+    syndromes = _i8(syndromes).reshape(-1, m)
+    B = syndromes.shape[0]
+    prior = _f64(prior)
+    assert prior.size == n
+    mode, aval, seq = _alpha_args(alpha_mode, alpha)
+    err = np.zeros((B, n), np.int8)
+    llr = np.zeros((B, n), np.float64)
+    conv = np.zeros(B, np.uint8)
+    iters = np.zeros(B, np.int32)
+    lib().orc_minsum_decode_batch(C.c_int(m), C.c_int(n), _p(indptr, C.c_int32), _p(indices, C.c_int32), C.c_int64(B),
+                                  _p(syndromes, C.c_int8), _p(prior, C.c_double), C.c_int(max_iter), C.c_int(mode),
+                                  C.c_double(aval), _p(seq, C.c_double), C.c_int(seq.size), C.c_double(damping),
+                                  C.c_double(clip_llr), _p(err, C.c_int8), _p(llr, C.c_double), _p(conv, C.c_uint8),
+                                  _p(iters, C.c_int32), C.c_int(threads))
+    return err, conv, llr, iters
+
+
+def minsum_core_sparse(indptr, indices, n, Q, ssign, alpha):
+    indptr, indices = _i32(indptr), _i32(indices)
+    m = indptr.size - 1
+    Q, ssign = _f64(Q), _f64(ssign)
+    R = np.zeros(indices.size)
+    Rs = np.zeros(n)
+    lib().orc_minsum_core_sparse(C.c_int(m), C.c_int(n), _p(indptr, C.c_int32), _p(indices, C.c_int32),
+                                 _p(Q, C.c_double), _p(ssign, C.c_double), C.c_double(alpha), _p(R, C.c_double),
+                                 _p(Rs, C.c_double))
+    return R, Rs
+
+
+def minsum_core_dense(Q, ssign, mask, alpha):
+    Q = _f64(Q)
+    m, n = Q.shape
+    mask = _u8(mask)
+    ssign = _f64(ssign).reshape(-1)
+    R = np.zeros((m, n))
+    lib().orc_minsum_core_dense(C.c_int(m), C.c_int(n), _p(Q, C.c_double), _p(ssign, C.c_double), _p(mask, C.c_uint8),
+                                C.c_double(alpha), _p(R, C.c_double))
+    return R
+
+
+def bp_core_dense(Q, ssign, mask, clip_val):
+    Q = _f64(Q)
+    m, n = Q.shape
+    mask = _u8(mask)
+    ssign = _f64(ssign).reshape(-1)
+    R = np.zeros((m, n))
+    lib().orc_bp_core_dense(C.c_int(m), C.c_int(n), _p(Q, C.c_double), _p(ssign, C.c_double), _p(mask, C.c_uint8),
+                            C.c_double(clip_val), _p(R, C.c_double))
+    return R
+
+
+def minsum_dense_driver(H, syndrome, prior, max_iter=50, alpha=1.0, alpha_mode="dynamical", damping=1.0,
+                        clip_llr=20.0, alpha_estimation=False):
+    H = np.asarray(H)
+    m, n = H.shape
+    mask = _u8(H != 0)
+    syndrome, prior = _i8(syndrome), _f64(prior)
+    mode, aval, seq = _alpha_args(alpha_mode, alpha)
+    cand = np.zeros(n, np.int8)
+    vals = np.zeros(n)
+    conv = np.zeros(1, np.uint8)
+    Rest = np.zeros((m, n))
+    it = lib().orc_minsum_dense_driver(C.c_int(m), C.c_int(n), _p(mask, C.c_uint8), _p(syndrome, C.c_int8),
+                                       _p(prior, C.c_double), C.c_int(max_iter), C.c_int(mode), C.c_double(aval),
+                                       _p(seq, C.c_double), C.c_int(seq.size), C.c_double(damping), C.c_double(clip_llr),
+                                       C.c_int(int(alpha_estimation)), _p(cand, C.c_int8), _p(vals, C.c_double),
+                                       _p(conv, C.c_uint8), _p(Rest, C.c_double))
+    if alpha_estimation:
+        return cand, False, Rest, 0
+    return cand, bool(conv[0]), vals, it
+
+
+def bp_dense_driver(H, syndrome, prior, max_iter=50):
+    H = np.asarray(H)
+    m, n = H.shape
+    mask = _u8(H != 0)
+    syndrome, prior = _i8(syndrome), _f64(prior)
+    cand = np.zeros(n, np.int8)
+    vals = np.zeros(n)
+    conv = np.zeros(1, np.uint8)
+    it = lib().orc_bp_dense_driver(C.c_int(m), C.c_int(n), _p(mask, C.c_uint8), _p(syndrome, C.c_int8),
+                                   _p(prior, C.c_double), C.c_int(max_iter), _p(cand, C.c_int8), _p(vals, C.c_double),
+                                   _p(conv, C.c_uint8))
+    return cand, bool(conv[0]), vals, it
+
+
+def syndrome_check(indptr, indices, cand):
+    indptr, indices, cand = _i32(indptr), _i32(indices), _i8(cand)
+    m = indptr.size - 1
+    out = np.zeros(m, np.int8)
+    lib().orc_syndrome_check(C.c_int(m), _p(indptr, C.c_int32), _p(indices, C.c_int32), _p(cand, C.c_int8), _p(out, C.c_int8))
+    return out
+
+
+def gf2_elimination(A, b):
+    """Byte-matrix elimination; returns (A_red uint8, b_red uint8, pivot_rows, pivot_cols)."""
+    A = _u8(A).copy()
+    b = _u8(b).copy()
+    m, n = A.shape
+    pr = np.zeros(min(m, n) + 1, np.int64)
+    pc = np.zeros(min(m, n) + 1, np.int64)
+    k = lib().orc_gf2_elimination(C.c_int(m), C.c_int(n), _p(A, C.c_uint8), _p(b, C.c_uint8), _p(pr, C.c_int64), _p(pc, C.c_int64))
+    return A, b, pr[:k].copy(), pc[:k].copy()
+
+
+def pack_rows_u64(A):
+    A = _u8(A)
+    m, n = A.shape
+    nw = lib().orc_packed_words(C.c_int(n))
+    P = np.zeros((m, nw), np.uint64)
+    lib().orc_pack_rows_u64(C.c_int(m), C.c_int(n), _p(A, C.c_uint8), _p(P, C.c_uint64))
+    return P
+
+
+def gf2_elimination_packed(A, b):
+    A = _u8(A)
+    m, n = A.shape
+    P = pack_rows_u64(A)
+    b = _u8(b).copy()
+    pr = np.zeros(min(m, n) + 1, np.int64)
+    pc = np.zeros(min(m, n) + 1, np.int64)
+    k = lib().orc_gf2_elimination_packed(C.c_int(m), C.c_int(n), C.c_int(P.shape[1]), _p(P, C.c_uint64), _p(b, C.c_uint8),
+                                         _p(pr, C.c_int64), _p(pc, C.c_int64))
+    return P, b, pr[:k].copy(), pc[:k].copy()
+
+
+def argsort_abs(llr):
+    llr = _f64(llr)
+    o = np.zeros(llr.size, np.int32)
+    lib().orc_argsort_abs(C.c_int(llr.size), _p(llr, C.c_double), _p(o, C.c_int32))
+    return o
+
+
+def osd0(indptr, indices, n, syndrome, llr, hard, ordering=None):
+    indptr, indices = _i32(indptr), _i32(indices)
+    m = indptr.size - 1
+    syndrome, llr, hard = _i8(syndrome), _f64(llr), _i8(hard)
+    sol = np.zeros(n, np.int8)
+    op = None
+    if ordering is not None:
+        ordering = _i32(ordering)
+        op = _p(ordering, C.c_int32)
+    lib().orc_osd0(C.c_int(m), C.c_int(n), _p(indptr, C.c_int32), _p(indices, C.c_int32), _p(syndrome, C.c_int8),
+                   _p(llr, C.c_double), _p(hard, C.c_int8), op, _p(sol, C.c_int8))
+    return sol
+
+
+def prior_llrs(probs):
+    probs = _f64(probs)
+    out = np.zeros(probs.size)
+    with np.errstate(all="ignore"):
+        lib().orc_prior_llrs(C.c_int(probs.size), _p(probs, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def generate_noisy_circuit(ops, q1, q2, p, rv, rp, rt, cap):
+    ops, q1, q2 = _i32(ops), _i32(q1), _i32(q2)
+    rv, rp, rt = _f64(rv), _i32(rp), _i32(rt)
+    oo, o1, o2 = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    L = lib().orc_generate_noisy_circuit(C.c_int64(ops.size), _p(ops, C.c_int32), _p(q1, C.c_int32), _p(q2, C.c_int32),
+                                         C.c_double(p), _p(rv, C.c_double), _p(rp, C.c_int32), _p(rt, C.c_int32),
+                                         _p(oo, C.c_int32), _p(o1, C.c_int32), _p(o2, C.c_int32))
+    return int(L), oo, o1, o2
+
+
+def simulate_circuit(kind, ops, q1, q2, total_qubits, max_syn):
+    ops, q1, q2 = _i32(ops), _i32(q1), _i32(q2)
+    hist = np.zeros(max_syn, np.int8)
+    state = np.zeros(total_qubits, np.int8)
+    counts = np.zeros(2, np.int64)
+    fn = lib().orc_simulate_circuit_z if kind == "Z" else lib().orc_simulate_circuit_x
+    fn(C.c_int64(ops.size), _p(ops, C.c_int32), _p(q1, C.c_int32), _p(q2, C.c_int32), C.c_int(total_qubits),
+       C.c_int(max_syn), _p(hist, C.c_int8), _p(state, C.c_int8), _p(counts, C.c_int64))
+    return hist, state, int(counts[0]), int(counts[1])
+
+
+def sparsify_syndrome(hist, syn_count, pos, ptrs, num_checks):
+    hist, pos, ptrs = _i8(hist), _i32(pos), _i32(ptrs)
+    out = np.zeros(syn_count, np.int8)
+    lib().orc_sparsify_syndrome(_p(hist, C.c_int8), C.c_int64(syn_count), _p(pos, C.c_int32), _p(ptrs, C.c_int32),
+                                C.c_int(num_checks), _p(out, C.c_int8))
+    return out
+
+
+def extract_data_state(state, idx):
+    state, idx = _i8(state), _i32(idx)
+    out = np.zeros(idx.size, np.int8)
+    lib().orc_extract_data_state(_p(state, C.c_int8), _p(idx, C.c_int32), C.c_int(idx.size), _p(out, C.c_int8))
+    return out
+
+
+def dense_matvec_mod2(L, v):
+    L, v = _u8(L), _i8(v)
+    k, n = L.shape
+    out = np.zeros(k, np.int8)
+    lib().orc_dense_matvec_mod2(C.c_int(k), C.c_int(n), _p(L, C.c_uint8), _p(v, C.c_int8), _p(out, C.c_int8))
+    return out
+
+
+def run_trial(fx, p, rv, rp, rt):
+    """a13 run_trial_fast (noise/simulation.py:21-107) with explicit random arrays.  fx = circuit dict."""
+    cap = int(fx["max_circuit_size"])
+    L, oo, o1, o2 = generate_noisy_circuit(fx["base_ops"], fx["base_q1"], fx["base_q2"], p, rv, rp, rt, cap)
+    ops = np.concatenate([oo[:L], fx["suffix_ops"]])
+    q1 = np.concatenate([o1[:L], fx["suffix_q1"]])
+    q2 = np.concatenate([o2[:L], fx["suffix_q2"]])
+    tq = int(fx["total_qubits"])
+    hz, sz, ncz, _ = simulate_circuit("Z", ops, q1, q2, tq, int(fx["max_syndromes_x"]))
+    true_z = dense_matvec_mod2(fx["Lx"], extract_data_state(sz, fx["data_qubit_indices"]))
+    sparse_z = sparsify_syndrome(hz, ncz, fx["x_syn_positions"], fx["x_syn_ptrs"], int(fx["num_x_checks"]))
+    hx, sx, ncx, _ = simulate_circuit("X", ops, q1, q2, tq, int(fx["max_syndromes_z"]))
+    true_x = dense_matvec_mod2(fx["Lz"], extract_data_state(sx, fx["data_qubit_indices"]))
+    sparse_x = sparsify_syndrome(hx, ncx, fx["z_syn_positions"], fx["z_syn_ptrs"], int(fx["num_z_checks"]))
+    return sparse_z, true_z, sparse_x, true_x
+
+
+def philox(ctr, key):
+    ctr = np.ascontiguousarray(ctr, np.uint32)
+    key = np.ascontiguousarray(key, np.uint32)
+    out = np.zeros(4, np.uint32)
+    lib().orc_philox4x32_10(_p(ctr, C.c_uint32), _p(key, C.c_uint32), _p(out, C.c_uint32))
+    return out
+
+
+def bernoulli_threshold(p):
+    return int(lib().orc_bernoulli_threshold(C.c_double(p)))
+
+
+def cc_sample_errors(seed, shot, n, p):
+    err = np.zeros(n, np.int8)
+    lib().orc_cc_sample_errors(C.c_uint64(seed), C.c_uint64(shot), C.c_int(n), C.c_uint32(bernoulli_threshold(p)), _p(err, C.c_int8))
+    return err
+
+
+def cc_sample_decode_tally(indptr, indices, n, L, p, seed, shot_begin, count, max_iter=50, alpha=1.0,
+                           alpha_mode="dynamical", damping=1.0, clip_llr=20.0, use_osd=True, threads=1):
+    indptr, indices = _i32(indptr), _i32(indices)
+    m = indptr.size - 1
+    L = _u8(L)
+    k = L.shape[0]
+    mode, aval, seq = _alpha_args(alpha_mode, alpha)
+    tally = np.zeros(16, np.int64)
+    lib().orc_cc_sample_decode_tally(C.c_int(m), C.c_int(n), _p(indptr, C.c_int32), _p(indices, C.c_int32), C.c_int(k),
+                                     _p(L, C.c_uint8), C.c_double(p), C.c_uint64(seed), C.c_int64(shot_begin),
+                                     C.c_int64(count), C.c_int(max_iter), C.c_int(mode), C.c_double(aval),
+                                     _p(seq, C.c_double), C.c_int(seq.size), C.c_double(damping), C.c_double(clip_llr),
+                                     C.c_int(int(use_osd)), C.c_int(threads), _p(tally, C.c_int64))
+    return tally

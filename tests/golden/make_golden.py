@@ -1,0 +1,438 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE'S OWN SOURCE.
+
+Container-only tool.  /root/reference does not exist on the GPU box and nothing in the
+test-suite, smoke() or bench.py imports this file.  It executes the reference's Python
+functions (src/decoding/*, src/noise/*, src/codes/*) under CPython with
+tools/refshim/numba (identity ``@njit``; numba itself is not installable here), i.e. the
+strict IEEE-754 reading of the reference source.  Every fixture stores its inputs
+explicitly (graphs, syndromes, priors, random arrays) together with the outputs the
+reference produced, so the other side never re-derives anything from a NumPy seed.
+
+Usage (from anywhere):  python3 tests/golden/make_golden.py [--only NAME]
+
+Also re-packs the reference's *data files* (codes/*.npz, two matrix_cache/*.npz) into
+compact CSR/bit form under qldpc-branched-off_amd/data/ (data, not source).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REPO, "tools", "refshim"))
+sys.path.insert(0, REF)
+
+from scipy.sparse import csr_matrix  # noqa: E402
+
+from src.decoding import kernels as K  # noqa: E402
+from src.decoding.sparse import performMinSum_Symmetric_Sparse  # noqa: E402
+from src.decoding.dense import performMinSum_Symmetric, performBeliefPropagationFast  # noqa: E402
+from src.decoding import osd as OSD  # noqa: E402
+from src.codes.bb_code import BBCodeCircuit  # noqa: E402
+from src.noise.compiled import CompiledCircuit  # noqa: E402
+from src.noise import kernels as NK  # noqa: E402
+from src.noise.simulation import run_trial_fast  # noqa: E402
+
+DATA = os.path.join(REPO, "qldpc-branched-off_amd", "data")
+CODES = {
+    "bb72": "codes/[[72, 12, 6]].npz",
+    "bb144": "codes/[[144, 12, 12]].npz",
+    "bb288": "codes/[[288, 12, 18]].npz",
+    "bb90": "codes/[[90, 8, 10]].npz",
+    "bb108": "codes/[[108, 8, 10]].npz",
+}
+CACHE = {
+    "circ72": ("matrix_cache/matrices_61d7ee9cf7e4c9ee.npz", "bb72", 6, 0.005),
+    "circ144": ("matrix_cache/matrices_d63ef327adf94be6.npz", "bb144", 12, 0.005),
+}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def csr_of(H):
+    c = csr_matrix(np.asarray(H))
+    c.sort_indices()
+    return c
+
+
+def load_code(tag):
+    d = np.load(os.path.join(REF, CODES[tag]))
+    return {k: d[k] for k in d.files}
+
+
+# --------------------------------------------------------------------------- data re-pack
+def pack_data():
+    os.makedirs(DATA, exist_ok=True)
+    out = {}
+    st = np.load(os.path.join(REF, "codes/steane.npz"))
+    out["steane_Hx"] = st["Hx"].astype(np.uint8)
+    out["steane_Hz"] = st["Hz"].astype(np.uint8)
+    for tag in CODES:
+        d = load_code(tag)
+        for k in ("Hx", "Hz", "Lx", "Lz"):
+            out[f"{tag}_{k}"] = d[k].astype(np.uint8)
+        out[f"{tag}_params"] = np.array([int(d["ell"]), int(d["m"]), int(d["distance"])], dtype=np.int64)
+        for k in ("a_x_powers", "a_y_powers", "b_y_powers", "b_x_powers"):
+            out[f"{tag}_{k}"] = d[k].astype(np.int64)
+    np.savez_compressed(os.path.join(DATA, "codes.npz"), **out)
+    print("  wrote data/codes.npz")
+    for tag, (path, code, cycles, p) in CACHE.items():
+        d = np.load(os.path.join(REF, path))
+        o = {"num_cycles": np.int64(cycles), "error_rate": np.float64(p),
+             "k": np.int64(d["k"][0]), "code": np.array(code)}
+        for s in ("Z", "X"):
+            Hd = csr_of(d[f"Hdec{s}"])
+            flr = int(d[f"first_logical_row{s}"][0])
+            k = int(d["k"][0])
+            Hl = csr_of(d[f"H{s}_full"][flr:flr + k])
+            o[f"Hdec{s}_shape"] = np.array(Hd.shape, dtype=np.int64)
+            o[f"Hdec{s}_indptr"] = Hd.indptr.astype(np.int32)
+            o[f"Hdec{s}_indices"] = Hd.indices.astype(np.int32)
+            o[f"H{s}_logical_indptr"] = Hl.indptr.astype(np.int32)
+            o[f"H{s}_logical_indices"] = Hl.indices.astype(np.int32)
+            o[f"channel_probs{s}"] = d[f"channel_probs{s}"].astype(np.float64)
+        np.savez_compressed(os.path.join(DATA, f"{tag}_p005.npz"), **o)
+        print(f"  wrote data/{tag}_p005.npz")
+
+
+# --------------------------------------------------------------------------- a1 / a2
+def run_sparse(Hc, synd, prior, **kw):
+    e, c, v, it = performMinSum_Symmetric_Sparse(Hc, synd, prior, **kw)
+    return np.asarray(e, np.int8), bool(c), np.asarray(v, np.float64), int(it)
+
+
+def batch_sparse(Hc, synds, prior, **kw):
+    E, C, V, I = [], [], [], []
+    for s in synds:
+        e, c, v, it = run_sparse(Hc, s, prior, **kw)
+        E.append(e); C.append(c); V.append(v); I.append(it)
+    return (np.array(E, np.int8), np.array(C, np.uint8), np.array(V, np.float64), np.array(I, np.int32))
+
+
+def gen_steane():
+    H = np.load(os.path.join(REF, "codes/steane.npz"))["Hx"]
+    Hc = csr_of(H)
+    prior = np.full(7, np.log((1 - 0.01) / 0.01))
+    synds = np.array([[(s >> b) & 1 for b in range(3)] for s in range(8)], dtype=np.int8)
+    out = dict(indptr=Hc.indptr.astype(np.int32), indices=Hc.indices.astype(np.int32),
+               m=np.int64(3), n=np.int64(7), prior=prior, syndromes=synds, max_iter=np.int64(10))
+    modes = {
+        "dyn": dict(alpha=1.0, alpha_mode="dynamical"),
+        "const": dict(alpha=0.8, alpha_mode="alvarado"),
+        "seq": dict(alpha=np.array([0.5, 0.7, 0.9]), alpha_mode="alvarado-autoregressive"),
+        "none0": dict(alpha=0, alpha_mode=None),      # None + alpha==0 -> dynamic
+        "none1": dict(alpha=0.9, alpha_mode=None),    # None + alpha!=0 -> constant
+    }
+    for tag, kw in modes.items():
+        E, C, V, I = batch_sparse(Hc, synds, prior, maxIter=10, **kw)
+        out[f"{tag}_err"], out[f"{tag}_conv"], out[f"{tag}_llr"], out[f"{tag}_iter"] = E, C, V, I
+    out["seq_alpha"] = np.array([0.5, 0.7, 0.9])
+    # non-uniform prior incl. a negative and a zero entry
+    prior2 = np.array([2.0, -0.5, 0.0, 3.25, 1.0, 4.0, 0.125])
+    E, C, V, I = batch_sparse(Hc, synds, prior2, maxIter=10, alpha=1.0, alpha_mode="dynamical")
+    out["prior2"] = prior2
+    out["p2_err"], out["p2_conv"], out["p2_llr"], out["p2_iter"] = E, C, V, I
+    save("steane_minsum", **out)
+
+
+def gen_bb(tag, nsyn, rng):
+    d = load_code(tag)
+    out = {}
+    for hname in ("Hx", "Hz"):
+        H = d[hname]
+        Hc = csr_of(H)
+        m, n = H.shape
+        out[f"{hname}_indptr"] = Hc.indptr.astype(np.int32)
+        out[f"{hname}_indices"] = Hc.indices.astype(np.int32)
+        out[f"{hname}_shape"] = np.array([m, n], np.int64)
+        for p in (0.005, 0.03, 0.08):
+            ptag = f"{hname}_p{int(round(p * 1000)):03d}"
+            errs = (rng.random((nsyn, n)) < p).astype(np.int8)
+            synds = (errs @ H.T % 2).astype(np.int8)          # law of alpha.py:127-128
+            prior = np.full(n, np.log((1 - p) / p))
+            out[f"{ptag}_errors"] = errs
+            out[f"{ptag}_syndromes"] = synds
+            out[f"{ptag}_prior"] = prior
+            for mi in (1, 5, 50):
+                E, C, V, I = batch_sparse(Hc, synds, prior, maxIter=mi, alpha=1.0, alpha_mode="dynamical")
+                k = f"{ptag}_dyn_it{mi}"
+                out[k + "_err"], out[k + "_conv"], out[k + "_llr"], out[k + "_iter"] = E, C, V, I
+            if hname == "Hx":
+                variants = {
+                    "const": dict(alpha=0.8, alpha_mode="alvarado"),
+                    "seq": dict(alpha=np.array([0.6, 0.7, 0.8, 0.9, 0.95]), alpha_mode="alvarado-autoregressive"),
+                    "damp": dict(alpha=1.0, alpha_mode="dynamical", damping=0.7),
+                    "clip5": dict(alpha=1.0, alpha_mode="dynamical", clip_llr=5.0),
+                    "dampclip": dict(alpha=0.9, alpha_mode="alvarado", damping=0.5, clip_llr=6.0),
+                }
+                for vtag, kw in variants.items():
+                    E, C, V, I = batch_sparse(Hc, synds, prior, maxIter=30, **kw)
+                    k = f"{ptag}_{vtag}"
+                    out[k + "_err"], out[k + "_conv"], out[k + "_llr"], out[k + "_iter"] = E, C, V, I
+    out["seq_alpha"] = np.array([0.6, 0.7, 0.8, 0.9, 0.95])
+    save(f"{tag}_minsum", **out)
+
+
+# --------------------------------------------------------------------------- a3 a4 a5 a6
+def gen_core():
+    rng = np.random.default_rng(20260301)
+    d = load_code("bb72")
+    H = d["Hx"]
+    Hc = csr_of(H)
+    m, n = H.shape
+    nnz = Hc.nnz
+    out = dict(indptr=Hc.indptr.astype(np.int32), indices=Hc.indices.astype(np.int32), shape=np.array([m, n], np.int64))
+    Q = rng.normal(0, 4, size=(6, nnz))
+    Q[1, :10] = 0.0                       # exact zeros (sign convention val>=0 -> +1)
+    Q[2, 5] = -0.0                        # negative zero counts as >= 0
+    Q[3, 7:9] = Q[3, 6]                   # duplicated magnitude inside one row (tie -> first wins)
+    Q[4, 0:6] = np.array([1.5, -1.5, 1.5, 2.0, -1.5, 9.0])
+    Q[5, 3] = np.inf
+    ssign = np.where(rng.random((6, m)) < 0.3, -1.0, 1.0)
+    alphas = np.array([1.0, 0.5, 0.75, 0.8, 0.9375, 0.3])
+    Rf, Rs, Rd = [], [], []
+    Hd = H.astype(np.float64)
+    mask = Hd != 0
+    for t in range(6):
+        r, s = K.minsum_core_sparse(Hc.data.astype(np.int8), Hc.indices.astype(np.int32), Hc.indptr.astype(np.int32),
+                                    Q[t].copy(), ssign[t].copy(), float(alphas[t]), m, n)
+        Rf.append(r); Rs.append(s)
+        Qd = np.zeros((m, n)); Qd[mask] = Q[t]          # row-major fill == CSR order
+        Rd.append(K.minsum_core(Hd, Qd, ssign[t].reshape(-1, 1).copy(), mask, float(alphas[t])))
+    out.update(Q=Q, syndrome_sign=ssign, alphas=alphas, R_flat=np.array(Rf), R_sum=np.array(Rs), R_dense=np.array(Rd))
+    # a5: bp_core single pass + driver runs
+    Qb = rng.normal(0, 2, size=(3, nnz))
+    Qb[1, :4] = 0.0
+    Qb[2, :6] = np.array([40.0, -38.0, 1e-20, 3.0, -2.0, 0.5])
+    Rb = []
+    for t in range(3):
+        Qd = np.zeros((m, n)); Qd[mask] = Qb[t]
+        Rb.append(K.bp_core(Hd, Qd, ssign[t].reshape(-1, 1).copy(), mask, 0.9999999))
+    out.update(bp_Q=Qb, bp_R_dense=np.array(Rb))
+    p = 0.03
+    errs = (rng.random((24, n)) < p).astype(np.int8)
+    synds = (errs @ H.T % 2).astype(np.int8)
+    prior = np.full(n, np.log((1 - p) / p))
+    E, C, V, I = [], [], [], []
+    for s in synds:
+        e, c, v, it = performBeliefPropagationFast(Hd, s, prior, maxIter=12)
+        E.append(np.asarray(e, np.int8)); C.append(bool(c)); V.append(v); I.append(int(it))
+    out.update(bpdrv_syndromes=synds, bpdrv_prior=prior, bpdrv_err=np.array(E, np.int8),
+               bpdrv_conv=np.array(C, np.uint8), bpdrv_llr=np.array(V), bpdrv_iter=np.array(I, np.int32))
+    # a4 driver: dense entry point incl. alpha_estimation
+    E, C, V, I = [], [], [], []
+    for s in synds:
+        e, c, v, it = performMinSum_Symmetric(Hd, s, prior, maxIter=12)
+        E.append(np.asarray(e, np.int8)); C.append(bool(c)); V.append(v); I.append(int(it))
+    out.update(dense_err=np.array(E, np.int8), dense_conv=np.array(C, np.uint8), dense_llr=np.array(V),
+               dense_iter=np.array(I, np.int32))
+    e, c, v, it = performMinSum_Symmetric(Hd, synds[3], prior, maxIter=12, alpha_estimation=True)
+    out.update(alphaest_R=np.asarray(v, np.float64), alphaest_iter=np.int64(it), alphaest_conv=np.uint8(c))
+    # a6 syndrome_check
+    cand = (rng.random((8, n)) < 0.2).astype(np.int8)
+    sc = np.array([K.syndrome_check(Hc.data.astype(np.int8), Hc.indices.astype(np.int32), Hc.indptr.astype(np.int32), c_, m)
+                   for c_ in cand], np.int8)
+    out.update(sc_candidates=cand, sc_syndromes=sc)
+    save("core_passes", **out)
+
+
+# --------------------------------------------------------------------------- a7 a8
+def gen_gf2():
+    rng = np.random.default_rng(77)
+    out = {}
+    cases = {
+        "r20x70": (rng.random((20, 70)) < 0.3),
+        "r64x64": (rng.random((64, 64)) < 0.5),
+        "r65x129": (rng.random((65, 129)) < 0.2),
+        "r70x20": (rng.random((70, 20)) < 0.4),
+        "r33x64": (rng.random((33, 64)) < 0.1),
+        "zeros": np.zeros((5, 9), bool),
+        "ident": np.eye(12, 17, dtype=bool),
+    }
+    A = (rng.random((30, 90)) < 0.3)
+    A[10:20] = A[0:10] ^ A[20:30]               # rank deficient
+    cases["rankdef"] = A
+    for tag, A in cases.items():
+        A = A.astype(np.int64)
+        b = (rng.random(A.shape[0]) < 0.5).astype(np.int64)
+        Aw, bw = A.copy(), b.copy()
+        Ar, br, pr, pc = K.gf2_elimination(Aw, bw)
+        Aw2, bw2 = A.copy(), b.copy()
+        Ap, bp, pr2, pc2 = K.gf2_elimination_packed(Aw2, bw2)
+        assert np.array_equal(br, bp) and np.array_equal(pr, pr2) and np.array_equal(pc, pc2)
+        out[f"{tag}_A"] = A.astype(np.uint8); out[f"{tag}_b"] = b.astype(np.uint8)
+        out[f"{tag}_A_red"] = np.asarray(Ar).astype(np.uint8); out[f"{tag}_b_red"] = np.asarray(br).astype(np.uint8)
+        out[f"{tag}_A_packed_red"] = np.asarray(Ap, dtype=np.uint64)
+        out[f"{tag}_pivot_rows"] = np.asarray(pr, np.int64); out[f"{tag}_pivot_cols"] = np.asarray(pc, np.int64)
+    out["cases"] = np.array(list(cases.keys()))
+    save("gf2_elimination", **out)
+
+
+# --------------------------------------------------------------------------- circuit level
+def build_circuit(tag):
+    path, code, cycles, p = CACHE[tag]
+    d = load_code(code)
+    bb = {k: d[k] for k in ("ell", "m", "a_x_powers", "a_y_powers", "b_y_powers", "b_x_powers")}
+    bb["ell"] = int(bb["ell"]); bb["m"] = int(bb["m"])
+    cb = BBCodeCircuit(d["Hx"], d["Hz"], num_cycles=cycles, **bb)
+    comp = CompiledCircuit(base_circuit=cb.get_full_circuit(), noiseless_suffix=cb.cycle * 2,
+                           lin_order=cb.lin_order, data_qubits=cb.data_qubits, Xchecks=cb.Xchecks, Zchecks=cb.Zchecks)
+    return d, cb, comp
+
+
+def gen_noise(tag, ndraw):
+    """a10-a13: op arrays + explicit randoms -> noisy circuit, histories, sparse syndromes, logicals."""
+    path, code, cycles, _ = CACHE[tag]
+    d, cb, comp = build_circuit(tag)
+    Lx, Lz = d["Lx"], d["Lz"]
+    out = dict(
+        base_ops=comp.base_ops, base_q1=comp.base_q1, base_q2=comp.base_q2,
+        suffix_ops=comp.suffix_ops, suffix_q1=comp.suffix_q1, suffix_q2=comp.suffix_q2,
+        total_qubits=np.int64(comp.total_qubits), num_error_locs=np.int64(comp.num_error_locs),
+        max_circuit_size=np.int64(comp.max_circuit_size),
+        x_syn_positions=comp.x_syn_positions, x_syn_ptrs=comp.x_syn_ptrs,
+        z_syn_positions=comp.z_syn_positions, z_syn_ptrs=comp.z_syn_ptrs,
+        x_check_indices=comp.x_check_indices, x_check_ptrs=comp.x_check_ptrs,
+        z_check_indices=comp.z_check_indices, z_check_ptrs=comp.z_check_ptrs,
+        data_qubit_indices=comp.data_qubit_indices,
+        max_syndromes_x=np.int64(comp.max_syndromes_x), max_syndromes_z=np.int64(comp.max_syndromes_z),
+        num_x_checks=np.int64(comp.num_x_checks), num_z_checks=np.int64(comp.num_z_checks),
+        Lx=Lx.astype(np.uint8), Lz=Lz.astype(np.uint8), num_cycles=np.int64(cycles),
+    )
+    n_locs = comp.num_error_locs
+    ps = [0.005] * (ndraw // 2) + [0.05] * (ndraw - ndraw // 2)
+    rv, rp, rt = [], [], []
+    nlen, nops, nq1, nq2 = [], [], [], []
+    hz, sz, hx, sx = [], [], [], []
+    spz, tz, spx, tx = [], [], [], []
+    cnt = []
+    for t, p in enumerate(ps):
+        np.random.seed(9000 + t)
+        # same draw order as noise/simulation.py:43-45
+        a = np.random.random(n_locs)
+        b = np.random.randint(0, 3, n_locs, dtype=np.int32)
+        c = np.random.randint(0, 15, n_locs, dtype=np.int32)
+        rv.append(a); rp.append(b); rt.append(c)
+        L = NK.generate_noisy_circuit_jit(comp.base_ops, comp.base_q1, comp.base_q2, p, a, b, c,
+                                          comp.out_ops, comp.out_q1, comp.out_q2)
+        nlen.append(L)
+        pad = comp.max_circuit_size
+        o = np.zeros(pad, np.int32); o[:L] = comp.out_ops[:L]; nops.append(o)
+        o = np.zeros(pad, np.int32); o[:L] = comp.out_q1[:L]; nq1.append(o)
+        o = np.zeros(pad, np.int32); o[:L] = comp.out_q2[:L]; nq2.append(o)
+        full_ops = np.concatenate([comp.out_ops[:L], comp.suffix_ops]).astype(np.int32)
+        full_q1 = np.concatenate([comp.out_q1[:L], comp.suffix_q1]).astype(np.int32)
+        full_q2 = np.concatenate([comp.out_q2[:L], comp.suffix_q2]).astype(np.int32)
+        h, s, nc, ne = NK.simulate_circuit_Z_jit(full_ops, full_q1, full_q2, comp.total_qubits,
+                                                 comp.x_check_indices, comp.x_check_ptrs, comp.max_syndromes_x)
+        hz.append(h.copy()); sz.append(s.copy()); cz = (nc, ne)
+        h2, s2, nc2, ne2 = NK.simulate_circuit_X_jit(full_ops, full_q1, full_q2, comp.total_qubits,
+                                                     comp.z_check_indices, comp.z_check_ptrs, comp.max_syndromes_z)
+        hx.append(h2.copy()); sx.append(s2.copy())
+        cnt.append([cz[0], cz[1], nc2, ne2])
+        # the composed trial, re-seeded so run_trial_fast draws the very same arrays
+        np.random.seed(9000 + t)
+        a_, b_, c_, d_ = run_trial_fast(comp, p, Lx, Lz)
+        spz.append(np.asarray(a_, np.int8)); tz.append(np.asarray(b_, np.int8))
+        spx.append(np.asarray(c_, np.int8)); tx.append(np.asarray(d_, np.int8))
+        # cross-check pieces against the composed call
+        assert np.array_equal(NK.sparsify_syndrome_jit(h, nc, comp.x_syn_positions, comp.x_syn_ptrs, comp.num_x_checks), a_)
+        assert np.array_equal((Lx @ NK.extract_data_state_jit(s, comp.data_qubit_indices)) % 2, b_)
+    out.update(error_rates=np.array(ps), random_vals=np.array(rv), random_paulis=np.array(rp, np.int32),
+               random_two_qubit=np.array(rt, np.int32), noisy_len=np.array(nlen, np.int64),
+               noisy_ops=np.array(nops, np.int32), noisy_q1=np.array(nq1, np.int32), noisy_q2=np.array(nq2, np.int32),
+               hist_z=np.array(hz, np.int8), state_z=np.array(sz, np.int8), hist_x=np.array(hx, np.int8),
+               state_x=np.array(sx, np.int8), counts=np.array(cnt, np.int64),
+               sparse_z=np.array(spz, np.int8), true_z=np.array(tz, np.int8),
+               sparse_x=np.array(spx, np.int8), true_x=np.array(tx, np.int8))
+    save(f"{tag}_noise", **out)
+    return out
+
+
+def prior_llrs(probs):
+    with np.errstate(divide="ignore", invalid="ignore"):        # engine.py:210-212
+        return np.clip(np.nan_to_num(np.log((1 - probs) / probs)), -50, 50)
+
+
+def gen_circuit_decode(tag, noise, ndec, n_osd, max_iter):
+    """a1 on the circuit-level graphs + a9 OSD-0 (and the np.argsort order it used) + a15 priors."""
+    path, code, cycles, _ = CACHE[tag]
+    m = np.load(os.path.join(REF, path))
+    out = {}
+    sel = [i for i in range(len(noise["error_rates"])) if noise["error_rates"][i] == 0.005][:ndec]
+    for s, spk in (("Z", "sparse_z"), ("X", "sparse_x")):
+        Hd = m[f"Hdec{s}"]
+        Hc = csr_of(Hd)
+        llr = prior_llrs(m[f"channel_probs{s}"])
+        out[f"llrs_{s}"] = llr
+        synds = noise[spk][sel]
+        t0 = time.time()
+        E, C, V, I = batch_sparse(Hc, synds, llr, maxIter=max_iter, alpha=1.0, alpha_mode="dynamical")
+        print(f"    {tag} {s}: {len(sel)} decodes in {time.time() - t0:.1f}s conv={C.tolist()} iters={I.tolist()}")
+        out[f"{s}_syndromes"] = synds.astype(np.int8)
+        out[f"{s}_err"], out[f"{s}_conv"], out[f"{s}_llr"], out[f"{s}_iter"] = E, C, V, I
+        # OSD-0 on the first n_osd non-converged decodes (reference call: engine.py:96-97, osd.py:5-29)
+        fails = [i for i in range(len(sel)) if not C[i]][:n_osd]
+        Hf = np.asarray(Hd, dtype=np.float64)
+        sols, orders = [], []
+        real_argsort = np.argsort
+        for i in fails:
+            cap = {}
+
+            def spy(a, *aa, **kk):
+                r = real_argsort(a, *aa, **kk)
+                cap.setdefault("o", r.copy())
+                return r
+            OSD.np.argsort = spy          # observe (not alter) the ordering osd.py:12 computes
+            try:
+                t0 = time.time()
+                sol = performOSD = OSD.performOSD_enhanced(Hf, synds[i], V[i], E[i], order=0)
+            finally:
+                OSD.np.argsort = real_argsort
+            print(f"      OSD-0 {tag} {s} case {i}: {time.time() - t0:.1f}s")
+            sols.append(np.asarray(sol, np.int64)); orders.append(cap["o"].astype(np.int64))
+        out[f"{s}_osd_cases"] = np.array(fails, np.int64)
+        out[f"{s}_osd_solution"] = np.array(sols, np.int64).reshape(len(fails), -1)
+        out[f"{s}_osd_ordering"] = np.array(orders, np.int64).reshape(len(fails), -1)
+    out["max_iter"] = np.int64(max_iter)
+    out["noise_rows"] = np.array(sel, np.int64)
+    save(f"{tag}_decode", **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    todo = a.only.split(",") if a.only else ["data", "steane", "bb", "core", "gf2", "circ72", "circ144"]
+    t0 = time.time()
+    if "data" in todo:
+        print("[data]"); pack_data()
+    if "steane" in todo:
+        print("[steane]"); gen_steane()
+    if "bb" in todo:
+        rng = np.random.default_rng(20260206)
+        for tag, nsyn in (("bb72", 64), ("bb144", 64), ("bb288", 32)):
+            print(f"[{tag}]"); gen_bb(tag, nsyn, rng)
+    if "core" in todo:
+        print("[core]"); gen_core()
+    if "gf2" in todo:
+        print("[gf2]"); gen_gf2()
+    if "circ72" in todo:
+        print("[circ72]"); nz = gen_noise("circ72", 8); gen_circuit_decode("circ72", nz, 4, 3, 50)
+    if "circ144" in todo:
+        print("[circ144]"); nz = gen_noise("circ144", 4); gen_circuit_decode("circ144", nz, 2, 1, 50)
+    print(f"done in {time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__":
+    main()

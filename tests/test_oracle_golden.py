@@ -1,0 +1,180 @@
+"""CPU suite: the oracle (oracle/qldpc_oracle.c) against the golden vectors the reference's own
+source produced (tests/golden/make_golden.py).  This is what PINS the oracle."""
+import numpy as np
+import pytest
+
+from conftest import assert_llr_close
+
+VARIANT_KW = {
+    "const": dict(alpha=0.8, alpha_mode="alvarado"),
+    "damp": dict(alpha=1.0, alpha_mode="dynamical", damping=0.7),
+    "clip5": dict(alpha=1.0, alpha_mode="dynamical", clip_llr=5.0),
+    "dampclip": dict(alpha=0.9, alpha_mode="alvarado", damping=0.5, clip_llr=6.0),
+}
+
+
+def check_decode(out, g, key, exact=True):
+    err, conv, llr, it = out
+    assert np.array_equal(err, g[key + "_err"])
+    assert np.array_equal(conv, g[key + "_conv"])
+    assert np.array_equal(it, g[key + "_iter"])
+    if exact:      # same operation order in strict IEEE f64 -> bit identical, stronger than the 1e-5 contract
+        assert np.array_equal(llr, g[key + "_llr"], equal_nan=True)
+    assert_llr_close(llr, g[key + "_llr"])
+
+
+def test_steane_all_syndromes(oracle, golden):
+    g = golden("steane_minsum")
+    mi = int(g["max_iter"])
+    modes = {
+        "dyn": dict(alpha=1.0, alpha_mode="dynamical"),
+        "const": dict(alpha=0.8, alpha_mode="alvarado"),
+        "seq": dict(alpha=g["seq_alpha"], alpha_mode="alvarado-autoregressive"),
+        "none0": dict(alpha=0, alpha_mode=None),
+        "none1": dict(alpha=0.9, alpha_mode=None),
+    }
+    for tag, kw in modes.items():
+        out = oracle.minsum_decode_batch(g["indptr"], g["indices"], 7, g["syndromes"], g["prior"], max_iter=mi, **kw)
+        check_decode(out, g, tag)
+    out = oracle.minsum_decode_batch(g["indptr"], g["indices"], 7, g["syndromes"], g["prior2"], max_iter=mi)
+    check_decode(out, g, "p2")
+
+
+@pytest.mark.parametrize("tag", ["bb72", "bb144", "bb288"])
+def test_bb_code_capacity(oracle, golden, tag):
+    g = golden(tag + "_minsum")
+    for h in ("Hx", "Hz"):
+        ip, ix = g[h + "_indptr"], g[h + "_indices"]
+        n = int(g[h + "_shape"][1])
+        for p in ("p005", "p030", "p080"):
+            base = f"{h}_{p}"
+            synd, prior = g[base + "_syndromes"], g[base + "_prior"]
+            for mi in (1, 5, 50):
+                out = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=mi)
+                check_decode(out, g, f"{base}_dyn_it{mi}")
+            if h == "Hx":
+                for v, kw in VARIANT_KW.items():
+                    out = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=30, **kw)
+                    check_decode(out, g, f"{base}_{v}")
+                out = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=30, alpha=g["seq_alpha"],
+                                                 alpha_mode="alvarado-autoregressive")
+                check_decode(out, g, f"{base}_seq")
+
+
+def test_golden_exercises_hard_cases(golden):
+    """The fixtures must contain multi-iteration and non-converged decodes, not only 1-iteration ones."""
+    g = golden("bb144_minsum")
+    assert (g["Hx_p080_dyn_it50_conv"] == 0).any()
+    assert (g["Hx_p030_dyn_it50_iter"] > 2).any()
+    assert (g["Hx_p005_dyn_it50_conv"] == 1).all()
+
+
+def test_core_passes(oracle, golden):
+    g = golden("core_passes")
+    m, n = (int(x) for x in g["shape"])
+    ip, ix = g["indptr"], g["indices"]
+    mask = np.zeros((m, n), bool)
+    for i in range(m):
+        mask[i, ix[ip[i]:ip[i + 1]]] = True
+    for t in range(g["Q"].shape[0]):
+        R, Rs = oracle.minsum_core_sparse(ip, ix, n, g["Q"][t], g["syndrome_sign"][t], float(g["alphas"][t]))
+        assert np.array_equal(R, g["R_flat"][t], equal_nan=True)
+        assert np.array_equal(Rs, g["R_sum"][t], equal_nan=True)
+        Qd = np.zeros((m, n)); Qd[mask] = g["Q"][t]
+        Rd = oracle.minsum_core_dense(Qd, g["syndrome_sign"][t], mask, float(g["alphas"][t]))
+        assert np.array_equal(Rd, g["R_dense"][t], equal_nan=True)
+    for t in range(g["bp_Q"].shape[0]):
+        Qd = np.zeros((m, n)); Qd[mask] = g["bp_Q"][t]
+        Rb = oracle.bp_core_dense(Qd, g["syndrome_sign"][t], mask, 0.9999999)
+        assert_llr_close(Rb, g["bp_R_dense"][t], tol=1e-5)     # libm tanh/atanh vs numpy's: ulps apart
+    sc = np.array([oracle.syndrome_check(ip, ix, c) for c in g["sc_candidates"]])
+    assert np.array_equal(sc, g["sc_syndromes"])
+
+
+def test_dense_and_bp_drivers(oracle, golden):
+    g = golden("core_passes")
+    m, n = (int(x) for x in g["shape"])
+    ip, ix = g["indptr"], g["indices"]
+    H = np.zeros((m, n))
+    for i in range(m):
+        H[i, ix[ip[i]:ip[i + 1]]] = 1.0
+    for t, s in enumerate(g["bpdrv_syndromes"]):
+        e, c, v, it = oracle.minsum_dense_driver(H, s, g["bpdrv_prior"], max_iter=12)
+        assert np.array_equal(e, g["dense_err"][t]) and c == bool(g["dense_conv"][t]) and it == g["dense_iter"][t]
+        assert np.array_equal(v, g["dense_llr"][t], equal_nan=True)
+        e, c, v, it = oracle.bp_dense_driver(H, s, g["bpdrv_prior"], max_iter=12)
+        assert np.array_equal(e, g["bpdrv_err"][t]) and c == bool(g["bpdrv_conv"][t]) and it == g["bpdrv_iter"][t]
+        assert_llr_close(v, g["bpdrv_llr"][t], tol=1e-5)
+    e, c, R, it = oracle.minsum_dense_driver(H, g["bpdrv_syndromes"][3], g["bpdrv_prior"], max_iter=12, alpha_estimation=True)
+    assert it == 0 and c is False and not e.any()
+    assert np.array_equal(R, g["alphaest_R"], equal_nan=True)
+
+
+def test_dense_equals_sparse_entry_point(oracle, golden):
+    """dense and sparse min-sum paths agree bit for bit."""
+    g = golden("core_passes")
+    m, n = (int(x) for x in g["shape"])
+    e, c, v, it = oracle.minsum_decode_batch(g["indptr"], g["indices"], n, g["bpdrv_syndromes"], g["bpdrv_prior"], max_iter=12)
+    assert np.array_equal(e, g["dense_err"]) and np.array_equal(c, g["dense_conv"]) and np.array_equal(it, g["dense_iter"])
+    assert np.array_equal(v, g["dense_llr"], equal_nan=True)
+
+
+def test_gf2_elimination(oracle, golden):
+    g = golden("gf2_elimination")
+    for tag in g["cases"]:
+        A, b = g[f"{tag}_A"], g[f"{tag}_b"]
+        Ar, br, pr, pc = oracle.gf2_elimination(A, b)
+        assert np.array_equal(Ar, g[f"{tag}_A_red"]) and np.array_equal(br, g[f"{tag}_b_red"])
+        assert np.array_equal(pr, g[f"{tag}_pivot_rows"]) and np.array_equal(pc, g[f"{tag}_pivot_cols"])
+        P, bp, pr2, pc2 = oracle.gf2_elimination_packed(A, b)
+        assert np.array_equal(P, g[f"{tag}_A_packed_red"]) and np.array_equal(bp, g[f"{tag}_b_red"])
+        assert np.array_equal(pr2, pr) and np.array_equal(pc2, pc)
+
+
+@pytest.mark.parametrize("tag", ["circ72", "circ144"])
+def test_noise_kernels(oracle, golden, tag):
+    g = golden(tag + "_noise")
+    cap = int(g["max_circuit_size"])
+    tq = int(g["total_qubits"])
+    for t, p in enumerate(g["error_rates"]):
+        L, oo, o1, o2 = oracle.generate_noisy_circuit(g["base_ops"], g["base_q1"], g["base_q2"], float(p),
+                                                      g["random_vals"][t], g["random_paulis"][t], g["random_two_qubit"][t], cap)
+        assert L == g["noisy_len"][t]
+        assert np.array_equal(oo[:L], g["noisy_ops"][t][:L]) and np.array_equal(o1[:L], g["noisy_q1"][t][:L])
+        assert np.array_equal(o2[:L], g["noisy_q2"][t][:L])
+        ops = np.concatenate([oo[:L], g["suffix_ops"]]); q1 = np.concatenate([o1[:L], g["suffix_q1"]])
+        q2 = np.concatenate([o2[:L], g["suffix_q2"]])
+        hz, sz, ncz, ecz = oracle.simulate_circuit("Z", ops, q1, q2, tq, int(g["max_syndromes_x"]))
+        hx, sx, ncx, ecx = oracle.simulate_circuit("X", ops, q1, q2, tq, int(g["max_syndromes_z"]))
+        assert np.array_equal(hz, g["hist_z"][t]) and np.array_equal(sz, g["state_z"][t])
+        assert np.array_equal(hx, g["hist_x"][t]) and np.array_equal(sx, g["state_x"][t])
+        assert [ncz, ecz, ncx, ecx] == g["counts"][t].tolist()
+        a, b, c, d = oracle.run_trial(g, float(p), g["random_vals"][t], g["random_paulis"][t], g["random_two_qubit"][t])
+        assert np.array_equal(a, g["sparse_z"][t]) and np.array_equal(b, g["true_z"][t])
+        assert np.array_equal(c, g["sparse_x"][t]) and np.array_equal(d, g["true_x"][t])
+    assert (g["sparse_z"].sum(axis=1) > 0).all()
+
+
+@pytest.mark.parametrize("tag", ["circ72", "circ144"])
+def test_circuit_level_decode_and_osd(oracle, golden, tag):
+    import os
+    from conftest import ROOT
+    g = golden(tag + "_decode")
+    with np.load(os.path.join(ROOT, "qldpc-branched-off_amd", "data", f"{tag}_p005.npz")) as d:
+        data = {k: d[k] for k in d.files}
+    for s in ("Z", "X"):
+        llr0 = oracle.prior_llrs(data[f"channel_probs{s}"])
+        assert np.array_equal(llr0, g[f"llrs_{s}"])                       # a15 incl. p_j > 1 -> 0
+        ip, ix = data[f"Hdec{s}_indptr"], data[f"Hdec{s}_indices"]
+        n = int(data[f"Hdec{s}_shape"][1])
+        out = oracle.minsum_decode_batch(ip, ix, n, g[f"{s}_syndromes"], llr0, max_iter=int(g["max_iter"]))
+        check_decode(out, g, s)
+        for t, case in enumerate(g[f"{s}_osd_cases"]):
+            sol = oracle.osd0(ip, ix, n, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case],
+                              ordering=g[f"{s}_osd_ordering"][t])
+            assert np.array_equal(sol, g[f"{s}_osd_solution"][t])
+            # the OSD-0 answer satisfies the syndrome
+            assert np.array_equal(oracle.syndrome_check(ip, ix, sol), g[f"{s}_syndromes"][case])
+    if tag == "circ144":
+        assert (data["channel_probsZ"] > 1).sum() == 1 and (g["llrs_Z"] == 0).sum() >= 1   # log(negative) -> NaN -> 0
+    assert np.isinf(g["X_llr"]).any()           # degree-1 checks -> +-inf posteriors (SURVEY hard parts)
