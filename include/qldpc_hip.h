@@ -1,0 +1,169 @@
+/*
+ * qldpc_hip.h -- C ABI of the MI355X (gfx950) qLDPC decoding / Monte-Carlo library.
+ *
+ * This is the drop-in boundary for the hot path of michelebanfi/qLDPC-branched-off: the reference's
+ * numba @njit kernels (src/decoding/kernels.py, src/noise/kernels.py) are what these entry points
+ * replace; the reference's Python wrappers (src/decoding/{sparse,dense,osd}.py, src/noise/simulation.py,
+ * src/simulation/engine.py) keep their names and call through ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - every function returns int: 0 = QLDPC_OK, negative = error; text via qldpc_last_error()
+ *     (thread-local).  Kernels never "raise": non-convergence is an output value, as in the reference.
+ *   - the caller owns every buffer; the library owns only opaque handles and its device workspaces.
+ *   - *_dev variants take DEVICE pointers (hipMalloc'ed or torch CUDA tensors' data_ptr()) and a
+ *     hipStream_t passed as void* (NULL = default stream); they enqueue work and do not synchronise.
+ *     The variants without _dev take HOST pointers, copy in/out and return when results are ready.
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
+ *     QLDPC_ERR_NO_DEVICE.
+ *   - matrices over GF(2) are CSR with sorted column indices (int32 indptr[m+1], indices[nnz]).
+ *   - batched arrays are shot-major: syndromes[B][m], errors[B][n], llr[B][n].
+ */
+#ifndef QLDPC_HIP_H
+#define QLDPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QLDPC_OK 0
+#define QLDPC_ERR_INVALID (-1)    /* bad argument (NULL, negative size, unsorted CSR, ...) */
+#define QLDPC_ERR_NO_DEVICE (-2)  /* no usable gfx950 device / HIP runtime error at init     */
+#define QLDPC_ERR_HIP (-3)        /* a HIP runtime call failed                              */
+#define QLDPC_ERR_UNSUPPORTED (-4)
+
+/* alpha schedule of the normalised min-sum (selection rules live in the Python wrappers,
+ * src/decoding/sparse.py:18-29):  CONST: alpha_k = alpha_val (kernels.py:275);
+ * DYNAMIC: alpha_k = 1 - 2^-(k+1) (kernels.py:273);  SEQ: alpha_k = seq[min(k,len-1)] (kernels.py:402-405). */
+#define QLDPC_ALPHA_CONST 0
+#define QLDPC_ALPHA_DYNAMIC 1
+#define QLDPC_ALPHA_SEQ 2
+
+/* decode flags */
+#define QLDPC_FLAG_FIXED_ITERS 0x1   /* execute all max_iter iterations for every shot; outputs are still
+                                        frozen at each shot's first converged iteration (identical results) */
+#define QLDPC_FLAG_KERNEL_STREAM 0x10   /* force the HBM-streaming kernel (any graph size)            */
+#define QLDPC_FLAG_KERNEL_RESIDENT 0x20 /* force the LDS/register-resident kernel (small graphs only) */
+
+/* tally slots written by the *_sample_decode_tally entry points (int64[QLDPC_TALLY_SLOTS]);
+ * replaces the Python tally loop of src/simulation/engine.py:450-457 */
+#define QLDPC_TALLY_SLOTS 16
+#define QLDPC_TALLY_TRIALS 0
+#define QLDPC_TALLY_Z_ERR 1       /* code capacity: logical errors of the single decoded sector */
+#define QLDPC_TALLY_X_ERR 2
+#define QLDPC_TALLY_TOTAL_ERR 3
+#define QLDPC_TALLY_BP_CONV_Z 4
+#define QLDPC_TALLY_BP_CONV_X 5
+#define QLDPC_TALLY_OSD_Z 6
+#define QLDPC_TALLY_OSD_X 7
+#define QLDPC_TALLY_ITERS_Z 8     /* sum over shots of (final_iter + 1) = iterations executed under reference semantics */
+#define QLDPC_TALLY_ITERS_X 9
+#define QLDPC_TALLY_ZERO_SYND_Z 10
+#define QLDPC_TALLY_ZERO_SYND_X 11
+#define QLDPC_TALLY_UNSAT_Z 12    /* decoder output (after OSD if enabled) does not reproduce the syndrome */
+#define QLDPC_TALLY_UNSAT_X 13
+
+typedef struct qldpc_graph qldpc_graph; /* Tanner graph: host CSR + CSC (ascending check order) + device copies */
+
+const char *qldpc_last_error(void);
+int qldpc_version(void);
+/* number of usable HIP devices (0 when none; never fails) */
+int qldpc_device_count(void);
+
+/* Build a Tanner-graph handle on `device`.  Validates the CSR (monotone indptr, 0 <= col < n, strictly
+ * increasing columns per row) and derives the CSC view with per-column ASCENDING check order, which is what
+ * reproduces the reference's scatter-add order R_sum[col] += msg (kernels.py:316).  Immutable afterwards. */
+int qldpc_graph_create(int m, int n, const int32_t *indptr, const int32_t *indices, int device, qldpc_graph **out);
+void qldpc_graph_destroy(qldpc_graph *g);
+int qldpc_graph_dims(const qldpc_graph *g, int *m, int *n, int *nnz);
+
+/* a1 + a2: minsum_decoder_full (src/decoding/kernels.py:234-366) and minsum_decoder_full_autoregressive
+ * (kernels.py:369-485), batched over B independent syndromes.  B = 1 backs performMinSum_Symmetric_Sparse
+ * (src/decoding/sparse.py:5-54).  Outputs per shot: candidateError int8[n], converged, values f64[n],
+ * final_iter (max_iter-1 when not converged).  alpha_seq may be NULL unless alpha_mode == SEQ. */
+int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *prior,
+                              int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq, int alpha_len,
+                              double damping, double clip_llr, int flags,
+                              int8_t *out_err, double *out_llr, uint8_t *out_conv, int32_t *out_iter);
+int qldpc_minsum_decode_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_syndromes, const double *d_prior,
+                                  int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq, int alpha_len,
+                                  double damping, double clip_llr, int flags,
+                                  int8_t *d_out_err, double *d_out_llr, uint8_t *d_out_conv, int32_t *d_out_iter,
+                                  void *stream);
+
+/* a3: minsum_core_sparse (kernels.py:138-169): one check-node pass; Q[B][nnz], syndrome_sign[B][m] (+-1.0)
+ * -> R[B][nnz], R_sum[B][n].  B = 1 is the reference call. */
+int qldpc_minsum_check_pass(const qldpc_graph *g, int64_t B, const double *Q, const double *syndrome_sign, double alpha,
+                            double *R, double *R_sum);
+/* a5: bp_core (kernels.py:171-193) on the same CSR edge layout: tanh-product rule, clip_val = 0.9999999 */
+int qldpc_bp_check_pass(const qldpc_graph *g, int64_t B, const double *Q, const double *syndrome_sign, double clip_val,
+                        double *R, double *R_sum);
+/* a5 driver: performBeliefPropagationFast (src/decoding/dense.py:75-96), batched */
+int qldpc_bp_decode_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *prior, int max_iter,
+                          int8_t *out_err, double *out_llr, uint8_t *out_conv, int32_t *out_iter);
+
+/* a6: GF(2) syndrome SpMV  s = H e (kernels.py:222-231, 352-359; H_csr.dot(e)%2 in alpha.py:128): vectors[B][n] -> out[B][m] */
+int qldpc_gf2_spmv_batch(const qldpc_graph *g, int64_t B, const int8_t *vectors, int8_t *out);
+
+/* a7: gf2_elimination (kernels.py:5-34): Gauss-Jordan on B byte matrices A[B][m][n] (0/1), b[B][m], in place.
+ * pivot_rows/pivot_cols: int64[B][min(m,n)], num_pivots int32[B]. */
+int qldpc_gf2_eliminate(int64_t B, int m, int n, uint8_t *A, uint8_t *b, int64_t *pivot_rows, int64_t *pivot_cols,
+                        int32_t *num_pivots);
+/* a8: gf2_elimination_packed_core (kernels.py:48-96) on rows packed little-endian into uint64 words
+ * (layout of _pack_rows_uint64, kernels.py:36-46): A[B][m][nwords], in place. */
+int qldpc_gf2_eliminate_packed(int64_t B, int m, int n, int nwords, uint64_t *A, uint8_t *b, int64_t *pivot_rows,
+                               int64_t *pivot_cols, int32_t *num_pivots);
+/* a9: performOSD_enhanced with order = 0 (src/decoding/osd.py:5-29), batched over B shots of one graph.
+ * ordering (int32[B][n], may be NULL): column order to eliminate in; NULL = ascending |llr| with ties broken by
+ * ascending index (np.argsort's default kind leaves ties implementation-defined, osd.py:12). solution int8[B][n]. */
+int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *llr, const int8_t *hard,
+                     const int32_t *ordering, int8_t *solution);
+
+/* a10: generate_noisy_circuit_jit (src/noise/kernels.py:175-353), batched over B draws of explicit random
+ * arrays rv/rp/rt [B][n_locs]; out_* [B][cap]; out_len int64[B]. */
+int qldpc_noisy_circuit_batch(int64_t B, int64_t len, const int32_t *ops, const int32_t *q1, const int32_t *q2, double p,
+                              int64_t n_locs, const double *rv, const int32_t *rp, const int32_t *rt, int64_t cap,
+                              int32_t *out_ops, int32_t *out_q1, int32_t *out_q2, int64_t *out_len);
+/* a11: simulate_circuit_Z_jit / simulate_circuit_X_jit (noise/kernels.py:13-91 / 94-172), batched over B op
+ * lists ops[B][cap] with lengths len[B]; hist int8[B][max_syn], state int8[B][total_qubits], counts int64[B][2]. */
+int qldpc_frame_sim_batch(int sector_is_x, int64_t B, int64_t cap, const int64_t *len, const int32_t *ops,
+                          const int32_t *q1, const int32_t *q2, int total_qubits, int max_syn, int8_t *hist, int8_t *state,
+                          int64_t *counts);
+/* a12: sparsify_syndrome_jit (noise/kernels.py:356-380), batched: hist[B][stride] -> out[B][stride] */
+int qldpc_sparsify_batch(int64_t B, int64_t stride, const int8_t *hist, const int64_t *syn_count, const int32_t *positions,
+                         const int32_t *ptrs, int num_checks, int8_t *out);
+
+/* Code-capacity Monte-Carlo (BASELINE configs 1-4), fused on the device: for global shots
+ * [shot_begin, shot_begin+count): sample e ~ Bernoulli(p)^n (law of src/decoding/alpha.py:127-128, Philox4x32-10
+ * stream keyed (seed, shot)), s = H e, decode (a1), OSD-0 on non-converged shots if use_osd, logical failure iff
+ * L (e xor e_hat) != 0 (rule of src/simulation/engine.py:99-100), tally.  L: dense k x n bytes (host).
+ * Host-synchronous: tally (host int64[16]) is complete on return.  Results are independent of how the shot range
+ * is split across calls / devices. */
+int qldpc_cc_sample_decode_tally(const qldpc_graph *g, int k, const uint8_t *L, double p, uint64_t seed,
+                                 int64_t shot_begin, int64_t count, int max_iter, int alpha_mode, double alpha_val,
+                                 const double *alpha_seq, int alpha_len, double damping, double clip_llr, int use_osd,
+                                 int flags, int64_t *tally);
+
+/* MC plan handle: same pipeline, asynchronous, for benchmarking and multi-stream use.  The plan owns device
+ * buffers sized for `batch` shots; qldpc_cc_plan_run enqueues one batch on `stream` accumulating into the plan's
+ * device tally; qldpc_cc_plan_read synchronises the stream and returns (and optionally clears) the tally. */
+typedef struct qldpc_cc_plan qldpc_cc_plan;
+int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t *L, double p, int max_iter, int alpha_mode,
+                         double alpha_val, const double *alpha_seq, int alpha_len, double damping, double clip_llr,
+                         int use_osd, int flags, int64_t batch, qldpc_cc_plan **out);
+int qldpc_cc_plan_run(qldpc_cc_plan *plan, uint64_t seed, int64_t shot_begin, int64_t count, void *stream);
+int qldpc_cc_plan_read(qldpc_cc_plan *plan, void *stream, int clear, int64_t *tally);
+/* time of the decode kernel launches enqueued since the last call, measured with hipEvents on the launch
+ * stream (ms, summed) and their count; used by bench.py for the roofline line. */
+int qldpc_cc_plan_kernel_time(qldpc_cc_plan *plan, double *ms_total, int64_t *launches);
+void qldpc_cc_plan_destroy(qldpc_cc_plan *plan);
+
+/* Philox4x32-10 reference vector helper (host; lets tests pin the generator against the oracle) */
+void qldpc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QLDPC_HIP_H */

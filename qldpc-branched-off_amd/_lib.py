@@ -1,0 +1,244 @@
+"""ctypes binding of csrc/libqldpc_hip.so (C ABI: include/qldpc_hip.h).  Fails loudly; no CPU fallback."""
+import ctypes as C
+import hashlib
+import os
+import threading
+from collections import OrderedDict
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libqldpc_hip.so")
+
+ALPHA_CONST, ALPHA_DYNAMIC, ALPHA_SEQ = 0, 1, 2
+FLAG_FIXED_ITERS, FLAG_KERNEL_STREAM, FLAG_KERNEL_RESIDENT = 0x1, 0x10, 0x20
+TALLY_SLOTS = 16
+TALLY = {"trials": 0, "z_err": 1, "x_err": 2, "total_err": 3, "bp_conv_z": 4, "bp_conv_x": 5, "osd_z": 6, "osd_x": 7,
+         "iters_z": 8, "iters_x": 9, "zero_synd_z": 10, "zero_synd_x": 11, "unsat_z": 12, "unsat_x": 13}
+
+EXPORTS = [
+    "qldpc_last_error", "qldpc_version", "qldpc_device_count", "qldpc_graph_create", "qldpc_graph_destroy", "qldpc_graph_dims",
+    "qldpc_minsum_decode_batch", "qldpc_minsum_decode_batch_dev", "qldpc_minsum_check_pass", "qldpc_bp_check_pass",
+    "qldpc_bp_decode_batch", "qldpc_gf2_spmv_batch", "qldpc_gf2_eliminate", "qldpc_gf2_eliminate_packed", "qldpc_osd0_batch",
+    "qldpc_noisy_circuit_batch", "qldpc_frame_sim_batch", "qldpc_sparsify_batch", "qldpc_cc_sample_decode_tally",
+    "qldpc_cc_plan_create", "qldpc_cc_plan_run", "qldpc_cc_plan_read", "qldpc_cc_plan_kernel_time", "qldpc_cc_plan_destroy",
+    "qldpc_philox4x32_10",
+]
+
+
+class QldpcError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(SO_PATH):
+                    raise QldpcError(f"HIP extension missing: {SO_PATH} (build it with `make -C {os.path.dirname(SO_PATH)}` "
+                                     "or __graft_entry__.build()); there is no CPU fallback")
+                L = C.CDLL(SO_PATH)
+                L.qldpc_last_error.restype = C.c_char_p
+                for name in EXPORTS:
+                    if name not in ("qldpc_last_error", "qldpc_graph_destroy", "qldpc_cc_plan_destroy", "qldpc_philox4x32_10"):
+                        getattr(L, name).restype = C.c_int
+                L.qldpc_graph_destroy.restype = None
+                L.qldpc_cc_plan_destroy.restype = None
+                L.qldpc_philox4x32_10.restype = None
+                _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().qldpc_last_error()
+        raise QldpcError(f"libqldpc_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def device_count():
+    return int(lib().qldpc_device_count())
+
+
+def require_device():
+    if device_count() <= 0:
+        raise QldpcError("no HIP device visible: libqldpc_hip runs on MI355X (gfx950) only and has no CPU fallback")
+
+
+def ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i8(a):
+    return np.ascontiguousarray(a, dtype=np.int8)
+
+
+def u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def alpha_args(alpha_mode, alpha):
+    """Alpha-mode rules of the reference wrappers (src/decoding/sparse.py:18-29,36-39; dense.py:19-33)."""
+    if alpha_mode is None:
+        mode = ALPHA_DYNAMIC if alpha == 0 else ALPHA_CONST
+    elif alpha_mode == "dynamical":
+        mode = ALPHA_DYNAMIC
+    elif alpha_mode == "alvarado":
+        if alpha <= 0:
+            raise ValueError("alpha must be > 0 when alpha_mode='alvarado'")
+        mode = ALPHA_CONST
+    elif alpha_mode == "alvarado-autoregressive":
+        mode = ALPHA_SEQ
+    else:
+        raise ValueError(f"Unsupported alpha_mode: {alpha_mode}")
+    if mode == ALPHA_SEQ:
+        seq = np.asarray(alpha, dtype=np.float64)
+        if seq.ndim != 1 or seq.size == 0:
+            raise ValueError("alpha must be a non-empty 1D sequence for alvarado-autoregressive")
+        return mode, 0.0, np.ascontiguousarray(seq)
+    return mode, float(alpha), np.zeros(1)
+
+
+class Graph:
+    """Owning wrapper of a qldpc_graph handle (Tanner graph of a parity-check matrix in canonical CSR)."""
+
+    def __init__(self, indptr, indices, n, device=0):
+        self.indptr, self.indices = i32(indptr), i32(indices)
+        self.m, self.n, self.nnz = self.indptr.size - 1, int(n), int(self.indices.size)
+        self.device = device
+        self._h = C.c_void_p()
+        require_device()
+        check(lib().qldpc_graph_create(C.c_int(self.m), C.c_int(self.n), ptr(self.indptr, C.c_int32), ptr(self.indices, C.c_int32),
+                                       C.c_int(device), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                lib().qldpc_graph_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+_graph_cache = OrderedDict()
+_GRAPH_CACHE_MAX = 16
+
+
+def canonical_csr(H):
+    """scipy sparse / dense array -> (indptr int32, indices int32 sorted per row, shape)."""
+    import scipy.sparse as sp
+    if sp.issparse(H):
+        c = H.tocsr()
+        if not c.has_sorted_indices:
+            c = c.sorted_indices()
+        if (c.data == 0).any():
+            c = c.copy()
+            c.eliminate_zeros()
+        return c.indptr.astype(np.int32), c.indices.astype(np.int32), c.shape
+    H = np.asarray(H)
+    m, n = H.shape
+    rows, cols = np.nonzero(H)
+    indptr = np.zeros(m + 1, np.int32)
+    np.add.at(indptr, rows + 1, 1)
+    return np.cumsum(indptr, dtype=np.int64).astype(np.int32), cols.astype(np.int32), (m, n)
+
+
+def graph_for(indptr, indices, n, device=0):
+    """Cached Graph for a CSR structure (the reference passes the same H on every trial)."""
+    indptr, indices = i32(indptr), i32(indices)
+    key = (device, int(n), hashlib.blake2b(indptr.tobytes() + indices.tobytes(), digest_size=16).digest())
+    g = _graph_cache.get(key)
+    if g is None:
+        g = Graph(indptr, indices, n, device)
+        _graph_cache[key] = g
+        while len(_graph_cache) > _GRAPH_CACHE_MAX:
+            _graph_cache.popitem(last=False)
+    else:
+        _graph_cache.move_to_end(key)
+    return g
+
+
+def minsum_decode_batch(graph, syndromes, prior, max_iter, alpha_mode, alpha, damping=1.0, clip_llr=20.0, flags=0):
+    """qldpc_minsum_decode_batch on host arrays -> (err int8[B,n], conv uint8[B], llr f64[B,n], iters int32[B])."""
+    mode, aval, seq = alpha_args(alpha_mode, alpha)
+    syndromes = i8(syndromes).reshape(-1, graph.m) if graph.m else np.zeros((np.asarray(syndromes).shape[0], 0), np.int8)
+    B = syndromes.shape[0]
+    prior = f64(prior)
+    if prior.size != graph.n:
+        raise ValueError(f"initialBelief has {prior.size} entries, H has {graph.n} columns")
+    err = np.zeros((B, graph.n), np.int8)
+    llr = np.zeros((B, graph.n), np.float64)
+    conv = np.zeros(B, np.uint8)
+    iters = np.zeros(B, np.int32)
+    check(lib().qldpc_minsum_decode_batch(graph.handle, C.c_int64(B), ptr(syndromes, C.c_int8), ptr(prior, C.c_double),
+                                          C.c_int(int(max_iter)), C.c_int(mode), C.c_double(aval), ptr(seq, C.c_double),
+                                          C.c_int(seq.size), C.c_double(float(damping)), C.c_double(float(clip_llr)), C.c_int(flags),
+                                          ptr(err, C.c_int8), ptr(llr, C.c_double), ptr(conv, C.c_uint8), ptr(iters, C.c_int32)))
+    return err, conv, llr, iters
+
+
+def cc_sample_decode_tally(graph, L, p, seed, shot_begin, count, max_iter=50, alpha=1.0, alpha_mode="dynamical", damping=1.0,
+                           clip_llr=20.0, use_osd=True, flags=0):
+    mode, aval, seq = alpha_args(alpha_mode, alpha)
+    L = u8(L).reshape(-1, graph.n)
+    tally = np.zeros(TALLY_SLOTS, np.int64)
+    check(lib().qldpc_cc_sample_decode_tally(graph.handle, C.c_int(L.shape[0]), ptr(L, C.c_uint8), C.c_double(p), C.c_uint64(seed),
+                                             C.c_int64(shot_begin), C.c_int64(count), C.c_int(max_iter), C.c_int(mode),
+                                             C.c_double(aval), ptr(seq, C.c_double), C.c_int(seq.size), C.c_double(damping),
+                                             C.c_double(clip_llr), C.c_int(int(use_osd)), C.c_int(flags), ptr(tally, C.c_int64)))
+    return tally
+
+
+class CodeCapacityPlan:
+    """Asynchronous code-capacity Monte-Carlo plan (qldpc_cc_plan_*): device-resident sample -> decode -> tally."""
+
+    def __init__(self, graph, L, p, max_iter=50, alpha=1.0, alpha_mode="dynamical", damping=1.0, clip_llr=20.0, use_osd=True,
+                 flags=0, batch=1 << 18):
+        mode, aval, seq = alpha_args(alpha_mode, alpha)
+        L = u8(L).reshape(-1, graph.n)
+        self.graph = graph
+        self._h = C.c_void_p()
+        check(lib().qldpc_cc_plan_create(graph.handle, C.c_int(L.shape[0]), ptr(L, C.c_uint8), C.c_double(p), C.c_int(max_iter),
+                                         C.c_int(mode), C.c_double(aval), ptr(seq, C.c_double), C.c_int(seq.size), C.c_double(damping),
+                                         C.c_double(clip_llr), C.c_int(int(use_osd)), C.c_int(flags), C.c_int64(batch), C.byref(self._h)))
+
+    def run(self, seed, shot_begin, count, stream=0):
+        check(lib().qldpc_cc_plan_run(self._h, C.c_uint64(seed), C.c_int64(shot_begin), C.c_int64(count), C.c_void_p(stream)))
+
+    def read(self, stream=0, clear=False):
+        tally = np.zeros(TALLY_SLOTS, np.int64)
+        check(lib().qldpc_cc_plan_read(self._h, C.c_void_p(stream), C.c_int(int(clear)), ptr(tally, C.c_int64)))
+        return tally
+
+    def kernel_time(self):
+        ms, nl = C.c_double(0), C.c_int64(0)
+        check(lib().qldpc_cc_plan_kernel_time(self._h, C.byref(ms), C.byref(nl)))
+        return ms.value, nl.value
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().qldpc_cc_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,105 @@
+// C-ABI entry points of the batched min-sum decoder (a1/a2) and kernel selection.
+#include "common.h"
+#include "minsum_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace qldpc {
+
+// alpha_k for k < max_iter, evaluated exactly as the reference does (src/decoding/kernels.py:272-275, 402-405).
+int build_alpha_table(int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq, int alpha_len,
+                      std::vector<double> &tab) {
+    QLDPC_REQUIRE(alpha_mode == QLDPC_ALPHA_CONST || alpha_mode == QLDPC_ALPHA_DYNAMIC || alpha_mode == QLDPC_ALPHA_SEQ,
+                  "unknown alpha_mode %d", alpha_mode);
+    if (alpha_mode == QLDPC_ALPHA_SEQ) QLDPC_REQUIRE(alpha_seq != nullptr && alpha_len > 0, "alpha_seq must be a non-empty sequence for QLDPC_ALPHA_SEQ");
+    tab.resize(max_iter > 0 ? max_iter : 1);
+    for (int k = 0; k < max_iter; k++) {
+        if (alpha_mode == QLDPC_ALPHA_DYNAMIC) tab[k] = 1.0 - std::ldexp(1.0, -(k + 1));   // 1.0 - 2.0**(-(k+1)), exact
+        else if (alpha_mode == QLDPC_ALPHA_SEQ) tab[k] = (k < alpha_len) ? alpha_seq[k] : alpha_seq[alpha_len - 1];
+        else tab[k] = alpha_val;
+    }
+    return QLDPC_OK;
+}
+
+bool resident_supported(const qldpc_graph *g, double damping);
+
+int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
+                           const double *d_alpha, double damping, double clip, int flags, int8_t *d_err, double *d_llr,
+                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
+    const bool want_stream = flags & QLDPC_FLAG_KERNEL_STREAM;
+    const bool want_res = flags & QLDPC_FLAG_KERNEL_RESIDENT;
+    const bool can_res = resident_supported(g, damping);
+    if (want_res && !can_res) {
+        set_error("resident kernel does not support this graph (m=%d n=%d max row degree %d, max column degree %d)", g->m, g->n,
+                  g->max_row_deg, g->max_col_deg);
+        return QLDPC_ERR_UNSUPPORTED;
+    }
+    if (!want_stream && can_res)
+        return minsum_resident_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
+    return minsum_stream_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
+}
+
+}  // namespace qldpc
+
+using namespace qldpc;
+
+static int check_decode_args(const qldpc_graph *g, int64_t B, const void *synd, const void *prior, int max_iter, double clip,
+                             const void *e, const void *l, const void *c, const void *it) {
+    QLDPC_REQUIRE(g != nullptr, "graph is NULL");
+    QLDPC_REQUIRE(B >= 0, "negative batch size");
+    QLDPC_REQUIRE(max_iter >= 0, "negative max_iter");
+    QLDPC_REQUIRE(!(clip != clip), "clip_llr is NaN");
+    if (B > 0) {
+        QLDPC_REQUIRE(prior != nullptr || g->n == 0, "prior is NULL");
+        QLDPC_REQUIRE(synd != nullptr || g->m == 0, "syndromes is NULL");
+        QLDPC_REQUIRE(e && l && c && it, "an output pointer is NULL");
+    }
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_minsum_decode_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior,
+                                               int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq,
+                                               int alpha_len, double damping, double clip_llr, int flags, int8_t *d_err,
+                                               double *d_llr, uint8_t *d_conv, int32_t *d_iter, void *stream) {
+    int rc = check_decode_args(g, B, d_synd, d_prior, max_iter, clip_llr, d_err, d_llr, d_conv, d_iter);
+    if (rc != QLDPC_OK) return rc;
+    if ((rc = use_device(g->device)) != QLDPC_OK) return rc;
+    if (B == 0) return QLDPC_OK;
+    std::vector<double> tab;
+    if ((rc = build_alpha_table(max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, tab)) != QLDPC_OK) return rc;
+    std::lock_guard<std::mutex> lk(g->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if ((rc = g->ws_alpha.ensure(tab.size() * sizeof(double))) != QLDPC_OK) return rc;
+    QLDPC_HIP_TRY(hipMemcpyAsync(g->ws_alpha.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    QLDPC_HIP_TRY(hipStreamSynchronize(s));   // tab is a stack temporary: the copy must have left host memory
+    return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, g->ws_alpha.as<double>(), damping, clip_llr, flags, d_err,
+                                  d_llr, d_conv, d_iter, s);
+}
+
+QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *prior,
+                                           int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq,
+                                           int alpha_len, double damping, double clip_llr, int flags, int8_t *out_err,
+                                           double *out_llr, uint8_t *out_conv, int32_t *out_iter) {
+    int rc = check_decode_args(g, B, syndromes, prior, max_iter, clip_llr, out_err, out_llr, out_conv, out_iter);
+    if (rc != QLDPC_OK) return rc;
+    if ((rc = use_device(g->device)) != QLDPC_OK) return rc;
+    if (B == 0) return QLDPC_OK;
+    const size_t m = g->m, n = g->n;
+    DevTmp d_synd, d_prior, d_err, d_llr, d_conv, d_iter;
+    if ((rc = d_synd.alloc(B * m)) || (rc = d_prior.alloc(n * 8)) || (rc = d_err.alloc(B * n)) || (rc = d_llr.alloc(B * n * 8)) ||
+        (rc = d_conv.alloc(B)) || (rc = d_iter.alloc(B * 4)))
+        return rc;
+    if (m) QLDPC_HIP_TRY(hipMemcpy(d_synd.p, syndromes, B * m, hipMemcpyHostToDevice));
+    if (n) QLDPC_HIP_TRY(hipMemcpy(d_prior.p, prior, n * 8, hipMemcpyHostToDevice));
+    rc = qldpc_minsum_decode_batch_dev(g, B, d_synd.as<int8_t>(), d_prior.as<double>(), max_iter, alpha_mode, alpha_val, alpha_seq,
+                                       alpha_len, damping, clip_llr, flags, d_err.as<int8_t>(), d_llr.as<double>(),
+                                       d_conv.as<uint8_t>(), d_iter.as<int32_t>(), nullptr);
+    if (rc != QLDPC_OK) return rc;
+    QLDPC_HIP_TRY(hipDeviceSynchronize());
+    if (n) QLDPC_HIP_TRY(hipMemcpy(out_err, d_err.p, B * n, hipMemcpyDeviceToHost));
+    if (n) QLDPC_HIP_TRY(hipMemcpy(out_llr, d_llr.p, B * n * 8, hipMemcpyDeviceToHost));
+    QLDPC_HIP_TRY(hipMemcpy(out_conv, d_conv.p, B, hipMemcpyDeviceToHost));
+    QLDPC_HIP_TRY(hipMemcpy(out_iter, d_iter.p, B * 4, hipMemcpyDeviceToHost));
+    return QLDPC_OK;
+}

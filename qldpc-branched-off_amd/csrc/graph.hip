@@ -1,0 +1,145 @@
+// Error state, device selection and the Tanner-graph handle of libqldpc_hip.
+#include "common.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace qldpc {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int use_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); libqldpc_hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        (void)hipGetLastError();
+        return QLDPC_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (have %d)", device, count);
+        return QLDPC_ERR_INVALID;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+        return QLDPC_ERR_NO_DEVICE;
+    }
+    return QLDPC_OK;
+}
+
+int DevBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return QLDPC_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        p = nullptr;
+        return QLDPC_ERR_HIP;
+    }
+    cap = bytes;
+    return QLDPC_OK;
+}
+
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+}  // namespace qldpc
+
+using namespace qldpc;
+
+QLDPC_EXPORT const char *qldpc_last_error(void) { return g_last_error.c_str(); }
+QLDPC_EXPORT int qldpc_version(void) { return 100; }
+
+QLDPC_EXPORT int qldpc_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+template <class T>
+static int upload(T **dst, const std::vector<T> &src) {
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    QLDPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+    if (!src.empty()) QLDPC_HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_graph_create(int m, int n, const int32_t *indptr, const int32_t *indices, int device, qldpc_graph **out) {
+    QLDPC_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    QLDPC_REQUIRE(m >= 0 && n >= 0, "negative dimensions m=%d n=%d", m, n);
+    QLDPC_REQUIRE(indptr != nullptr, "indptr is NULL");
+    QLDPC_REQUIRE(indptr[0] == 0, "indptr[0] must be 0");
+    for (int i = 0; i < m; i++) QLDPC_REQUIRE(indptr[i + 1] >= indptr[i], "indptr not monotone at row %d", i);
+    const int nnz = indptr[m];
+    QLDPC_REQUIRE(nnz == 0 || indices != nullptr, "indices is NULL");
+    for (int i = 0; i < m; i++)
+        for (int e = indptr[i]; e < indptr[i + 1]; e++) {
+            QLDPC_REQUIRE(indices[e] >= 0 && indices[e] < n, "column index %d out of range in row %d", indices[e], i);
+            QLDPC_REQUIRE(e == indptr[i] || indices[e] > indices[e - 1], "row %d: column indices must be strictly increasing (canonical CSR)", i);
+        }
+    int rc = use_device(device);
+    if (rc != QLDPC_OK) return rc;
+
+    qldpc_graph *g = new qldpc_graph();
+    g->m = m; g->n = n; g->nnz = nnz; g->device = device;
+    g->indptr.assign(indptr, indptr + m + 1);
+    g->indices.assign(indices, indices + nnz);
+    // CSC view, per column in ascending check order (rows are visited in ascending i)
+    g->colptr.assign(n + 1, 0);
+    for (int e = 0; e < nnz; e++) g->colptr[indices[e] + 1]++;
+    for (int j = 0; j < n; j++) g->colptr[j + 1] += g->colptr[j];
+    g->rowidx.resize(nnz); g->csc2csr.resize(nnz); g->csr2csc.resize(nnz);
+    std::vector<int32_t> fill(g->colptr.begin(), g->colptr.end() - 1);
+    for (int i = 0; i < m; i++) {
+        g->max_row_deg = std::max(g->max_row_deg, indptr[i + 1] - indptr[i]);
+        for (int e = indptr[i]; e < indptr[i + 1]; e++) {
+            const int k = fill[indices[e]]++;
+            g->rowidx[k] = i; g->csc2csr[k] = e; g->csr2csc[e] = k;
+        }
+    }
+    for (int j = 0; j < n; j++) g->max_col_deg = std::max(g->max_col_deg, g->colptr[j + 1] - g->colptr[j]);
+    rc = upload(&g->d_indptr, g->indptr);
+    if (rc == QLDPC_OK) rc = upload(&g->d_indices, g->indices);
+    if (rc == QLDPC_OK) rc = upload(&g->d_colptr, g->colptr);
+    if (rc == QLDPC_OK) rc = upload(&g->d_rowidx, g->rowidx);
+    if (rc == QLDPC_OK) rc = upload(&g->d_csc2csr, g->csc2csr);
+    if (rc == QLDPC_OK) rc = upload(&g->d_csr2csc, g->csr2csc);
+    if (rc != QLDPC_OK) { qldpc_graph_destroy(g); return rc; }
+    *out = g;
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT void qldpc_graph_destroy(qldpc_graph *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    for (int32_t *p : {g->d_indptr, g->d_indices, g->d_colptr, g->d_rowidx, g->d_csc2csr, g->d_csr2csc})
+        if (p) (void)hipFree(p);
+    g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_alpha.release(); g->ws_misc.release();
+    delete g;
+}
+
+QLDPC_EXPORT int qldpc_graph_dims(const qldpc_graph *g, int *m, int *n, int *nnz) {
+    QLDPC_REQUIRE(g != nullptr, "graph is NULL");
+    if (m) *m = g->m;
+    if (n) *n = g->n;
+    if (nnz) *nnz = g->nnz;
+    return QLDPC_OK;
+}

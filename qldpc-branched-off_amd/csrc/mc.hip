@@ -1,0 +1,305 @@
+// Code-capacity Monte-Carlo pipeline around the decoder: Philox sampler, GF(2) syndrome SpMV (a6),
+// failed-shot collection for OSD-0, logical-error judge and the int64 tally (replaces the Python tally loop
+// src/simulation/engine.py:450-457).  Sampling law: src/decoding/alpha.py:127-128; failure rule: engine.py:99-100.
+#include "common.h"
+#include "mc_common.h"
+#include "minsum_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace qldpc {
+
+// ---- sampler: one thread per (shot, 4-variable block); bit j is an error iff Philox word < thr ----
+__global__ void cc_sample_kernel(int64_t count, int64_t shot_begin, uint32_t seed_lo, uint32_t seed_hi, int n, uint32_t thr,
+                                 int8_t *__restrict__ err) {
+    const int nq = (n + 3) >> 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * nq) return;
+    const int64_t b = t / nq;
+    const int q = (int)(t - b * nq);
+    const uint64_t g = (uint64_t)(shot_begin + b);
+    uint32_t o[4];
+    philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)q, 0u, seed_lo, seed_hi, o);
+    int8_t *e = err + b * n + 4 * q;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+        if (4 * q + w < n) e[w] = (o[w] < thr) ? 1 : 0;
+}
+
+// ---- a6: s_i = XOR_{j in row i} e_j ; one thread per (shot, row) (kernels.py:222-231) ----
+__global__ void gf2_spmv_kernel(int64_t B, int m, int n, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                const int8_t *__restrict__ vec, int8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * m) return;
+    const int64_t b = t / m;
+    const int i = (int)(t - b * m);
+    const int8_t *v = vec + b * n;
+    int s = 0;
+    for (int e = indptr[i]; e < indptr[i + 1]; e++) s ^= v[indices[e]];
+    out[t] = (int8_t)(s & 1);
+}
+
+// ---- list the shots BP did not converge on (input of the OSD-0 stage) ----
+__global__ void collect_failed_kernel(int64_t B, const uint8_t *__restrict__ conv, int32_t *__restrict__ list, int32_t *__restrict__ count) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (!conv[b]) list[atomicAdd(count, 1)] = (int32_t)b;
+}
+
+// ---- judge: 32 lanes per shot; logical failure iff L (e xor e_hat) != 0; unsat iff H e_hat != s ----
+__global__ __launch_bounds__(256) void cc_judge_kernel(int64_t B, int m, int n, const int32_t *__restrict__ indptr,
+                                                       const int32_t *__restrict__ indices, const uint64_t *__restrict__ Lmask,
+                                                       const int8_t *__restrict__ err, const int8_t *__restrict__ synd,
+                                                       const int8_t *__restrict__ dec, const uint8_t *__restrict__ conv,
+                                                       const int32_t *__restrict__ iters, unsigned long long *__restrict__ tally) {
+    __shared__ unsigned long long acc[6];
+    if (threadIdx.x < 6) acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 31;
+    const int64_t b = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (b < B) {
+        const int8_t *e = err + b * n, *d = dec + b * n, *s = synd + b * m;
+        uint64_t lm = 0;
+        for (int j = lane; j < n; j += 32)
+            if ((e[j] ^ d[j]) & 1) lm ^= Lmask[j];
+        int bad = 0, nz = 0;
+        for (int i = lane; i < m; i += 32) {
+            int p = 0;
+            for (int k = indptr[i]; k < indptr[i + 1]; k++) p ^= d[indices[k]];
+            bad |= ((p ^ s[i]) & 1);
+            nz |= (s[i] & 1);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            lm ^= __shfl_xor(lm, off, 32);
+            bad |= __shfl_xor(bad, off, 32);
+            nz |= __shfl_xor(nz, off, 32);
+        }
+        if (lane == 0) {
+            if (lm != 0) atomicAdd(&acc[0], 1ull);
+            if (conv[b]) atomicAdd(&acc[1], 1ull);
+            atomicAdd(&acc[2], (unsigned long long)(iters[b] + 1));
+            if (!nz) atomicAdd(&acc[3], 1ull);
+            if (bad) atomicAdd(&acc[4], 1ull);
+            atomicAdd(&acc[5], 1ull);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (acc[0]) { atomicAdd(&tally[QLDPC_TALLY_Z_ERR], acc[0]); atomicAdd(&tally[QLDPC_TALLY_TOTAL_ERR], acc[0]); }
+        if (acc[1]) atomicAdd(&tally[QLDPC_TALLY_BP_CONV_Z], acc[1]);
+        if (acc[2]) atomicAdd(&tally[QLDPC_TALLY_ITERS_Z], acc[2]);
+        if (acc[3]) atomicAdd(&tally[QLDPC_TALLY_ZERO_SYND_Z], acc[3]);
+        if (acc[4]) atomicAdd(&tally[QLDPC_TALLY_UNSAT_Z], acc[4]);
+        if (acc[5]) atomicAdd(&tally[QLDPC_TALLY_TRIALS], acc[5]);
+    }
+}
+
+__global__ void add_osd_count_kernel(const int32_t *count, unsigned long long *tally) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&tally[QLDPC_TALLY_OSD_Z], (unsigned long long)*count);
+}
+
+int gf2_spmv_launch(const qldpc_graph *g, int64_t B, const int8_t *d_vec, int8_t *d_out, hipStream_t stream) {
+    const int64_t total = B * g->m;
+    if (total == 0) return QLDPC_OK;
+    hipLaunchKernelGGL(gf2_spmv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, B, g->m, g->n, g->d_indptr,
+                       g->d_indices, d_vec, d_out);
+    QLDPC_HIP_TRY(hipGetLastError());
+    return QLDPC_OK;
+}
+
+}  // namespace qldpc
+
+using namespace qldpc;
+
+// ------------------------------------------------------------------------------------------ plan
+struct qldpc_cc_plan {
+    const qldpc_graph *g = nullptr;
+    int k = 0, max_iter = 0, use_osd = 0, flags = 0;
+    double p = 0, damping = 1, clip = 20;
+    uint32_t thr = 0;
+    int64_t batch = 0;
+    std::vector<double> alpha;
+    DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decode-kernel brackets not yet read
+    std::vector<hipEvent_t> pool;
+    double ms_total = 0;
+    int64_t launches = 0;
+};
+
+static hipEvent_t get_event(qldpc_cc_plan *P) {
+    if (!P->pool.empty()) { hipEvent_t e = P->pool.back(); P->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t *L, double p, int max_iter, int alpha_mode,
+                                      double alpha_val, const double *alpha_seq, int alpha_len, double damping, double clip_llr,
+                                      int use_osd, int flags, int64_t batch, qldpc_cc_plan **out) {
+    QLDPC_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    QLDPC_REQUIRE(g != nullptr, "graph is NULL");
+    QLDPC_REQUIRE(k >= 0 && k <= 64, "k=%d logical rows unsupported (0..64)", k);
+    QLDPC_REQUIRE(k == 0 || L != nullptr, "L is NULL");
+    QLDPC_REQUIRE(p > 0.0 && p < 1.0, "error rate must be in (0,1)");
+    QLDPC_REQUIRE(batch > 0 && batch <= ((int64_t)1 << 30), "batch out of range");
+    QLDPC_REQUIRE(max_iter >= 0, "negative max_iter");
+    int rc = use_device(g->device);
+    if (rc != QLDPC_OK) return rc;
+    qldpc_cc_plan *P = new qldpc_cc_plan();
+    P->g = g; P->k = k; P->max_iter = max_iter; P->use_osd = use_osd; P->flags = flags;
+    P->p = p; P->damping = damping; P->clip = clip_llr; P->batch = batch;
+    P->thr = bernoulli_threshold(p);
+    if ((rc = build_alpha_table(max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, P->alpha)) != QLDPC_OK) { delete P; return rc; }
+    const size_t n = g->n, m = g->m;
+    std::vector<double> prior(n ? n : 1, std::log((1.0 - p) / p));     // uniform prior log((1-p)/p), alpha.py:119-120
+    std::vector<uint64_t> Lmask(n ? n : 1, 0);
+    for (int r = 0; r < k; r++)
+        for (size_t j = 0; j < n; j++)
+            if (L[(size_t)r * n + j] & 1) Lmask[j] |= (uint64_t)1 << r;
+    auto fail = [&](int code) { qldpc_cc_plan_destroy(P); return code; };
+    if ((rc = P->d_alpha.ensure(P->alpha.size() * 8)) || (rc = P->d_prior.ensure(prior.size() * 8)) ||
+        (rc = P->d_Lmask.ensure(Lmask.size() * 8)) || (rc = P->d_err.ensure(batch * n)) || (rc = P->d_synd.ensure(batch * m)) ||
+        (rc = P->d_dec.ensure(batch * n)) || (rc = P->d_llr.ensure(batch * n * 8)) || (rc = P->d_conv.ensure(batch)) ||
+        (rc = P->d_iter.ensure(batch * 4)) || (rc = P->d_tally.ensure(QLDPC_TALLY_SLOTS * 8)) ||
+        (rc = P->d_list.ensure(batch * 4)) || (rc = P->d_count.ensure(16)))
+        return fail(rc);
+    if (hipMemcpy(P->d_alpha.p, P->alpha.data(), P->alpha.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(P->d_prior.p, prior.data(), prior.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(P->d_Lmask.p, Lmask.data(), Lmask.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8) != hipSuccess) {
+        set_error("plan upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(QLDPC_ERR_HIP);
+    }
+    *out = P;
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot_begin, int64_t count, void *stream) {
+    QLDPC_REQUIRE(P != nullptr, "plan is NULL");
+    QLDPC_REQUIRE(count >= 0 && shot_begin >= 0, "negative shot range");
+    int rc = use_device(P->g->device);
+    if (rc != QLDPC_OK) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const qldpc_graph *g = P->g;
+    const int n = g->n, m = g->m;
+    for (int64_t off = 0; off < count; off += P->batch) {
+        const int64_t B = (count - off < P->batch) ? (count - off) : P->batch;
+        const int64_t nq = (n + 3) / 4;
+        if (B * nq > 0)
+            hipLaunchKernelGGL(cc_sample_kernel, dim3((unsigned)((B * nq + 255) / 256)), dim3(256), 0, s, B, shot_begin + off,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), n, P->thr, P->d_err.as<int8_t>());
+        QLDPC_HIP_TRY(hipGetLastError());
+        if ((rc = gf2_spmv_launch(g, B, P->d_err.as<int8_t>(), P->d_synd.as<int8_t>(), s)) != QLDPC_OK) return rc;
+        hipEvent_t e0 = get_event(P), e1 = get_event(P);
+        if (e0 && e1) QLDPC_HIP_TRY(hipEventRecord(e0, s));
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            rc = minsum_decode_dispatch(g, B, P->d_synd.as<int8_t>(), P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(),
+                                        P->damping, P->clip, P->flags, P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
+                                        P->d_conv.as<uint8_t>(), P->d_iter.as<int32_t>(), s);
+        }
+        if (rc != QLDPC_OK) return rc;
+        if (e0 && e1) { QLDPC_HIP_TRY(hipEventRecord(e1, s)); P->pending.emplace_back(e0, e1); }
+        if (P->use_osd) {
+            QLDPC_HIP_TRY(hipMemsetAsync(P->d_count.p, 0, 4, s));
+            hipLaunchKernelGGL(collect_failed_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, P->d_conv.as<uint8_t>(),
+                               P->d_list.as<int32_t>(), P->d_count.as<int32_t>());
+            QLDPC_HIP_TRY(hipGetLastError());
+            if ((rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), P->d_synd.as<int8_t>(),
+                                         P->d_llr.as<double>(), P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), s)) != QLDPC_OK)
+                return rc;
+            hipLaunchKernelGGL(add_osd_count_kernel, dim3(1), dim3(64), 0, s, P->d_count.as<int32_t>(),
+                               P->d_tally.as<unsigned long long>());
+        }
+        hipLaunchKernelGGL(cc_judge_kernel, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, B, m, n, g->d_indptr, g->d_indices,
+                           P->d_Lmask.as<uint64_t>(), P->d_err.as<int8_t>(), P->d_synd.as<int8_t>(), P->d_dec.as<int8_t>(),
+                           P->d_conv.as<uint8_t>(), P->d_iter.as<int32_t>(), P->d_tally.as<unsigned long long>());
+        QLDPC_HIP_TRY(hipGetLastError());
+    }
+    return QLDPC_OK;
+}
+
+static int drain_events(qldpc_cc_plan *P) {
+    for (auto &pr : P->pending) {
+        QLDPC_HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0;
+        QLDPC_HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        P->ms_total += ms; P->launches++;
+        P->pool.push_back(pr.first); P->pool.push_back(pr.second);
+    }
+    P->pending.clear();
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_cc_plan_read(qldpc_cc_plan *P, void *stream, int clear, int64_t *tally) {
+    QLDPC_REQUIRE(P != nullptr && tally != nullptr, "NULL argument");
+    int rc = use_device(P->g->device);
+    if (rc != QLDPC_OK) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    QLDPC_HIP_TRY(hipStreamSynchronize(s));
+    QLDPC_HIP_TRY(hipMemcpy(tally, P->d_tally.p, QLDPC_TALLY_SLOTS * 8, hipMemcpyDeviceToHost));
+    if (clear) QLDPC_HIP_TRY(hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8));
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_cc_plan_kernel_time(qldpc_cc_plan *P, double *ms_total, int64_t *launches) {
+    QLDPC_REQUIRE(P != nullptr, "plan is NULL");
+    int rc = drain_events(P);
+    if (rc != QLDPC_OK) return rc;
+    if (ms_total) *ms_total = P->ms_total;
+    if (launches) *launches = P->launches;
+    P->ms_total = 0; P->launches = 0;
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT void qldpc_cc_plan_destroy(qldpc_cc_plan *P) {
+    if (!P) return;
+    (void)hipSetDevice(P->g->device);
+    for (auto &pr : P->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : P->pool) (void)hipEventDestroy(e);
+    for (DevBuf *b : {&P->d_alpha, &P->d_prior, &P->d_Lmask, &P->d_err, &P->d_synd, &P->d_dec, &P->d_llr, &P->d_conv, &P->d_iter,
+                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol})
+        b->release();
+    delete P;
+}
+
+QLDPC_EXPORT int qldpc_cc_sample_decode_tally(const qldpc_graph *g, int k, const uint8_t *L, double p, uint64_t seed,
+                                              int64_t shot_begin, int64_t count, int max_iter, int alpha_mode, double alpha_val,
+                                              const double *alpha_seq, int alpha_len, double damping, double clip_llr, int use_osd,
+                                              int flags, int64_t *tally) {
+    QLDPC_REQUIRE(tally != nullptr, "tally is NULL");
+    QLDPC_REQUIRE(count >= 0, "negative count");
+    qldpc_cc_plan *P = nullptr;
+    int64_t batch = count < 1 ? 1 : (count < (1 << 18) ? count : (1 << 18));
+    int rc = qldpc_cc_plan_create(g, k, L, p, max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, damping, clip_llr, use_osd, flags,
+                                  batch, &P);
+    if (rc != QLDPC_OK) return rc;
+    rc = qldpc_cc_plan_run(P, seed, shot_begin, count, nullptr);
+    if (rc == QLDPC_OK) rc = qldpc_cc_plan_read(P, nullptr, 0, tally);
+    qldpc_cc_plan_destroy(P);
+    return rc;
+}
+
+QLDPC_EXPORT int qldpc_gf2_spmv_batch(const qldpc_graph *g, int64_t B, const int8_t *vectors, int8_t *out) {
+    QLDPC_REQUIRE(g != nullptr, "graph is NULL");
+    QLDPC_REQUIRE(B >= 0, "negative batch");
+    int rc = use_device(g->device);
+    if (rc != QLDPC_OK) return rc;
+    if (B == 0 || g->m == 0) return QLDPC_OK;
+    QLDPC_REQUIRE(vectors != nullptr && out != nullptr, "NULL buffer");
+    DevTmp dv, dout;
+    if ((rc = dv.alloc((size_t)B * g->n)) || (rc = dout.alloc((size_t)B * g->m))) return rc;
+    if (g->n) QLDPC_HIP_TRY(hipMemcpy(dv.p, vectors, (size_t)B * g->n, hipMemcpyHostToDevice));
+    if ((rc = gf2_spmv_launch(g, B, dv.as<int8_t>(), dout.as<int8_t>(), nullptr)) != QLDPC_OK) return rc;
+    QLDPC_HIP_TRY(hipDeviceSynchronize());
+    QLDPC_HIP_TRY(hipMemcpy(out, dout.p, (size_t)B * g->m, hipMemcpyDeviceToHost));
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT void qldpc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}

@@ -1,0 +1,44 @@
+// Philox4x32-10 counter-based generator and shared declarations of the Monte-Carlo pipeline.
+// Stream definition (a pure function of (seed, shot, block, domain), reproducible on any device):
+//   key = (seed_lo, seed_hi); counter = (shot_lo, shot_hi, block, domain).
+//   domain 0: code-capacity error bits -- bit j of a shot uses word (j & 3) of block (j >> 2); error iff word < thr,
+//   thr = floor(p * 2^32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <vector>
+
+struct qldpc_graph;
+
+namespace qldpc {
+
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                                       uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+inline uint32_t bernoulli_threshold(double p) {
+    if (p <= 0.0) return 0u;
+    if (p >= 1.0) return 0xFFFFFFFFu;
+    return (uint32_t)std::floor(p * 4294967296.0);
+}
+
+int build_alpha_table(int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq, int alpha_len, std::vector<double> &tab);
+int gf2_spmv_launch(const qldpc_graph *g, int64_t B, const int8_t *d_vec, int8_t *d_out, hipStream_t stream);
+
+// OSD-0 on the shots listed in d_list[0 .. *d_count) (device-resident count: no host sync).  d_ordering may be NULL
+// (stable ascending |llr|); otherwise int32[B][n] indexed by shot.  solution may alias hard.
+int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream);
+
+}  // namespace qldpc

@@ -1,0 +1,39 @@
+// Device helpers shared by the min-sum kernels.  All arithmetic is IEEE f64 in the reference's operand order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+struct qldpc_graph;
+
+namespace qldpc {
+
+// reference src/decoding/kernels.py:328-333: NaN -> 0, else clip to [-clip, clip]
+__device__ __forceinline__ double clip_nan(double q, double clip) {
+    if (q != q) return 0.0;
+    if (q > clip) return clip;
+    if (q < -clip) return -clip;
+    return q;
+}
+
+// reference src/decoding/kernels.py:339-342
+__device__ __forceinline__ double clip_only(double q, double clip) {
+    if (q > clip) return clip;
+    if (q < -clip) return -clip;
+    return q;
+}
+
+// Host-side launchers implemented by the kernel files.
+int minsum_stream_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
+                         const double *d_alpha, double damping, double clip, int flags, int8_t *d_err, double *d_llr,
+                         uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
+
+int minsum_resident_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
+                           const double *d_alpha, double damping, double clip, int flags, int8_t *d_err, double *d_llr,
+                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
+bool resident_supported(const qldpc_graph *g, double damping);
+int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
+                           const double *d_alpha, double damping, double clip, int flags, int8_t *d_err, double *d_llr,
+                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
+
+}  // namespace qldpc

@@ -1,0 +1,3 @@
+"""Circuit-level noise: same call surface as the reference's ``src/noise`` package (JIT path), computed on the GPU."""
+from .simulation import run_trial_fast  # noqa: F401
+from .compiled import CompiledCircuit  # noqa: F401

@@ -1,0 +1,105 @@
+"""CPU suite for the boundary: the C-ABI library loads and exports every symbol include/qldpc_hip.h declares, the
+Python mirror validates arguments like the reference, and the product path FAILS LOUDLY without a GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def L():
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "qldpc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qldpc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    lib = L.lib()
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    for s in decl:
+        assert hasattr(lib, s), f"{s} declared in include/qldpc_hip.h but not exported"
+    assert sorted(L.EXPORTS) == decl
+    out = subprocess.run(["nm", "-D", "--defined-only", L.SO_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert set(decl) <= exported
+    assert all(e.startswith("qldpc_") for e in exported if not e.startswith("_")), exported
+
+
+def test_version_and_host_helpers(L, oracle):
+    import ctypes as C
+    assert L.lib().qldpc_version() >= 100
+    assert L.device_count() >= 0
+    c = np.array([1, 2, 3, 4], np.uint32); k = np.array([5, 6], np.uint32); o = np.zeros(4, np.uint32)
+    L.lib().qldpc_philox4x32_10(L.ptr(c, C.c_uint32), L.ptr(k, C.c_uint32), L.ptr(o, C.c_uint32))
+    assert np.array_equal(o, oracle.philox(c, k))
+    # Random123 known-answer vectors for Philox4x32-10
+    for ctr, key, want in (([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+                           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+                           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+                            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])):
+        assert oracle.philox(ctr, key).tolist() == want
+
+
+def test_argument_validation_matches_reference(L):
+    from qldpc_amd.decoding.sparse import performMinSum_Symmetric_Sparse
+    from qldpc_amd.decoding.dense import performMinSum_Symmetric
+    H = np.eye(3)
+    for fn in (performMinSum_Symmetric_Sparse, performMinSum_Symmetric):
+        with pytest.raises(ValueError, match="Unsupported alpha_mode"):
+            fn(H, [0, 0, 0], [1.0, 1.0, 1.0], alpha_mode="bogus")
+        with pytest.raises(ValueError, match="alpha must be > 0"):
+            fn(H, [0, 0, 0], [1.0, 1.0, 1.0], alpha_mode="alvarado", alpha=0)
+        with pytest.raises(ValueError, match="non-empty 1D"):
+            fn(H, [0, 0, 0], [1.0, 1.0, 1.0], alpha_mode="alvarado-autoregressive", alpha=np.zeros((2, 2)))
+
+
+def test_no_cpu_fallback(L):
+    """Without a GPU the product path must raise, never compute."""
+    if L.device_count() > 0:
+        pytest.skip("GPU present")
+    from qldpc_amd.decoding.sparse import performMinSum_Symmetric_Sparse
+    with pytest.raises(L.QldpcError, match="no CPU fallback"):
+        performMinSum_Symmetric_Sparse(np.eye(3), [0, 0, 0], [1.0, 1.0, 1.0])
+    import ctypes as C
+    h = C.c_void_p()
+    ip = np.array([0, 1], np.int32); ix = np.array([0], np.int32)
+    rc = L.lib().qldpc_graph_create(1, 1, L.ptr(ip, C.c_int32), L.ptr(ix, C.c_int32), 0, C.byref(h))
+    assert rc == -2 and b"no CPU fallback" in L.lib().qldpc_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "qldpc-branched-off_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.lower(), f"{f} mentions the oracle"
+
+
+def test_canonical_csr_and_data(L):
+    import scipy.sparse as sp
+    from qldpc_amd.data import load_code, load_circuit_matrices
+    c = load_code("bb144")
+    assert c["Hx"].shape == (72, 144) and c["Hx_indptr"][-1] == 432 and c["Lx"].shape == (12, 144)
+    assert not ((c["Hx"].astype(int) @ c["Hz"].T.astype(int)) % 2).any()          # CSS commutation
+    assert not ((c["Hx"].astype(int) @ c["Lz"].T.astype(int)) % 2).any()
+    ip, ix, shape = L.canonical_csr(sp.csr_matrix(c["Hx"]))
+    assert np.array_equal(ip, c["Hx_indptr"]) and np.array_equal(ix, c["Hx_indices"])
+    ip2, ix2, _ = L.canonical_csr(c["Hx"].astype(float))
+    assert np.array_equal(ip2, ip) and np.array_equal(ix2, ix)
+    d = load_circuit_matrices("circ144")
+    assert tuple(d["HdecZ_shape"]) == (1008, 8785) and d["HdecZ_indptr"][-1] == 30672
