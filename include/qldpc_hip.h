@@ -45,7 +45,9 @@ extern "C" {
 #define QLDPC_FLAG_FIXED_ITERS 0x1   /* execute all max_iter iterations for every shot; outputs are still
                                         frozen at each shot's first converged iteration (identical results) */
 #define QLDPC_FLAG_KERNEL_STREAM 0x10   /* force the HBM-streaming kernel (any graph size)            */
-#define QLDPC_FLAG_KERNEL_RESIDENT 0x20 /* force the LDS/register-resident kernel (small graphs only) */
+#define QLDPC_FLAG_KERNEL_RESIDENT 0x20 /* force the LDS/register-resident kernels (small graphs only) */
+#define QLDPC_FLAG_KERNEL_GENERIC 0x40  /* resident family: use the generic (irregular-degree) kernel even for regular graphs */
+#define QLDPC_FLAG_MC_UNFUSED 0x80      /* Monte-Carlo plans: separate sample / decode / judge launches instead of the fused kernel */
 
 /* tally slots written by the *_sample_decode_tally entry points (int64[QLDPC_TALLY_SLOTS]);
  * replaces the Python tally loop of src/simulation/engine.py:450-457 */

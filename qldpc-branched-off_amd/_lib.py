@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libqldpc_hip.so")
 
 ALPHA_CONST, ALPHA_DYNAMIC, ALPHA_SEQ = 0, 1, 2
-FLAG_FIXED_ITERS, FLAG_KERNEL_STREAM, FLAG_KERNEL_RESIDENT = 0x1, 0x10, 0x20
+FLAG_FIXED_ITERS, FLAG_KERNEL_STREAM, FLAG_KERNEL_RESIDENT, FLAG_KERNEL_GENERIC, FLAG_MC_UNFUSED = 0x1, 0x10, 0x20, 0x40, 0x80
 TALLY_SLOTS = 16
 TALLY = {"trials": 0, "z_err": 1, "x_err": 2, "total_err": 3, "bp_conv_z": 4, "bp_conv_x": 5, "osd_z": 6, "osd_x": 7,
          "iters_z": 8, "iters_x": 9, "zero_synd_z": 10, "zero_synd_x": 11, "unsat_z": 12, "unsat_x": 13}

@@ -25,11 +25,13 @@ int build_alpha_table(int max_iter, int alpha_mode, double alpha_val, const doub
 bool resident_supported(const qldpc_graph *g, double damping);
 
 int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
-                           const double *d_alpha, double damping, double clip, int flags, int8_t *d_err, double *d_llr,
+                           const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
                            uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
     const bool want_stream = flags & QLDPC_FLAG_KERNEL_STREAM;
-    const bool want_res = flags & QLDPC_FLAG_KERNEL_RESIDENT;
+    const bool want_res = flags & (QLDPC_FLAG_KERNEL_RESIDENT | QLDPC_FLAG_KERNEL_GENERIC);
     const bool can_res = resident_supported(g, damping);
+    if (!want_stream && !(flags & QLDPC_FLAG_KERNEL_GENERIC) && regular_supported(g, clip))
+        return minsum_regular_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
     if (want_res && !can_res) {
         set_error("resident kernel does not support this graph (m=%d n=%d max row degree %d, max column degree %d)", g->m, g->n,
                   g->max_row_deg, g->max_col_deg);
@@ -58,9 +60,9 @@ static int check_decode_args(const qldpc_graph *g, int64_t B, const void *synd, 
     return QLDPC_OK;
 }
 
-QLDPC_EXPORT int qldpc_minsum_decode_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior,
+static int decode_dev_impl(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior,
                                                int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq,
-                                               int alpha_len, double damping, double clip_llr, int flags, int8_t *d_err,
+                                               int alpha_len, double damping, double clip_llr, int flags, bool prior_finite, int8_t *d_err,
                                                double *d_llr, uint8_t *d_conv, int32_t *d_iter, void *stream) {
     int rc = check_decode_args(g, B, d_synd, d_prior, max_iter, clip_llr, d_err, d_llr, d_conv, d_iter);
     if (rc != QLDPC_OK) return rc;
@@ -73,8 +75,19 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch_dev(const qldpc_graph *g, int64_t B, 
     if ((rc = g->ws_alpha.ensure(tab.size() * sizeof(double))) != QLDPC_OK) return rc;
     QLDPC_HIP_TRY(hipMemcpyAsync(g->ws_alpha.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
     QLDPC_HIP_TRY(hipStreamSynchronize(s));   // tab is a stack temporary: the copy must have left host memory
-    return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, g->ws_alpha.as<double>(), damping, clip_llr, flags, d_err,
+    bool nanfree = prior_finite && std::isfinite(clip_llr) && std::isfinite(damping);
+    for (double a : tab) nanfree = nanfree && std::isfinite(a);
+    return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, g->ws_alpha.as<double>(), damping, clip_llr, flags, nanfree, d_err,
                                   d_llr, d_conv, d_iter, s);
+}
+
+QLDPC_EXPORT int qldpc_minsum_decode_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior,
+                                               int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq,
+                                               int alpha_len, double damping, double clip_llr, int flags, int8_t *d_err,
+                                               double *d_llr, uint8_t *d_conv, int32_t *d_iter, void *stream) {
+    // the prior lives on the device: its finiteness is unknown here, so the NaN test of kernels.py:328 stays in
+    return decode_dev_impl(g, B, d_synd, d_prior, max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, damping, clip_llr, flags, false,
+                           d_err, d_llr, d_conv, d_iter, stream);
 }
 
 QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *prior,
@@ -92,9 +105,11 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, cons
         return rc;
     if (m) QLDPC_HIP_TRY(hipMemcpy(d_synd.p, syndromes, B * m, hipMemcpyHostToDevice));
     if (n) QLDPC_HIP_TRY(hipMemcpy(d_prior.p, prior, n * 8, hipMemcpyHostToDevice));
-    rc = qldpc_minsum_decode_batch_dev(g, B, d_synd.as<int8_t>(), d_prior.as<double>(), max_iter, alpha_mode, alpha_val, alpha_seq,
-                                       alpha_len, damping, clip_llr, flags, d_err.as<int8_t>(), d_llr.as<double>(),
-                                       d_conv.as<uint8_t>(), d_iter.as<int32_t>(), nullptr);
+    bool prior_finite = true;
+    for (size_t j = 0; j < n; j++) prior_finite = prior_finite && std::isfinite(prior[j]);
+    rc = decode_dev_impl(g, B, d_synd.as<int8_t>(), d_prior.as<double>(), max_iter, alpha_mode, alpha_val, alpha_seq,
+                         alpha_len, damping, clip_llr, flags, prior_finite, d_err.as<int8_t>(), d_llr.as<double>(),
+                         d_conv.as<uint8_t>(), d_iter.as<int32_t>(), nullptr);
     if (rc != QLDPC_OK) return rc;
     QLDPC_HIP_TRY(hipDeviceSynchronize());
     if (n) QLDPC_HIP_TRY(hipMemcpy(out_err, d_err.p, B * n, hipMemcpyDeviceToHost));

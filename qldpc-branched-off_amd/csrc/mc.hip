@@ -122,6 +122,7 @@ struct qldpc_cc_plan {
     int64_t batch = 0;
     std::vector<double> alpha;
     DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol;
+    bool fused = false, nanfree = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decode-kernel brackets not yet read
     std::vector<hipEvent_t> pool;
@@ -161,6 +162,10 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
         for (size_t j = 0; j < n; j++)
             if (L[(size_t)r * n + j] & 1) Lmask[j] |= (uint64_t)1 << r;
     auto fail = [&](int code) { qldpc_cc_plan_destroy(P); return code; };
+    P->nanfree = std::isfinite(clip_llr);
+    for (double a : P->alpha) P->nanfree = P->nanfree && std::isfinite(a);
+    P->fused = !(flags & (QLDPC_FLAG_MC_UNFUSED | QLDPC_FLAG_KERNEL_STREAM | QLDPC_FLAG_KERNEL_GENERIC)) && damping == 1.0 &&
+               regular_supported(g, clip_llr);
     if ((rc = P->d_alpha.ensure(P->alpha.size() * 8)) || (rc = P->d_prior.ensure(prior.size() * 8)) ||
         (rc = P->d_Lmask.ensure(Lmask.size() * 8)) || (rc = P->d_err.ensure(batch * n)) || (rc = P->d_synd.ensure(batch * m)) ||
         (rc = P->d_dec.ensure(batch * n)) || (rc = P->d_llr.ensure(batch * n * 8)) || (rc = P->d_conv.ensure(batch)) ||
@@ -188,6 +193,29 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
     const int n = g->n, m = g->m;
     for (int64_t off = 0; off < count; off += P->batch) {
         const int64_t B = (count - off < P->batch) ? (count - off) : P->batch;
+        if (P->fused) {
+            // one launch: sample -> syndrome -> decode -> logical compare -> tally; BP failures are exported for OSD-0.
+            // The failure records reuse the per-shot buffers of the unfused path (synd/err/dec/llr), compacted.
+            QLDPC_HIP_TRY(hipMemsetAsync(P->d_count.p, 0, 4, s));
+            hipEvent_t e0 = get_event(P), e1 = get_event(P);
+            if (e0 && e1) QLDPC_HIP_TRY(hipEventRecord(e0, s));
+            rc = mc_regular_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, P->nanfree, seed,
+                                   shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_tally.as<unsigned long long>(),
+                                   P->d_count.as<int32_t>(), P->d_list.as<int32_t>(), P->d_synd.as<int8_t>(), P->d_err.as<int8_t>(),
+                                   P->d_dec.as<int8_t>(), P->d_llr.as<double>(), s);
+            if (rc != QLDPC_OK) return rc;
+            if (e0 && e1) { QLDPC_HIP_TRY(hipEventRecord(e1, s)); P->pending.emplace_back(e0, e1); }
+            if (P->use_osd) {
+                std::lock_guard<std::mutex> lk(g->mu);
+                if ((rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), P->d_synd.as<int8_t>(), P->d_llr.as<double>(),
+                                             P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), s)) != QLDPC_OK)
+                    return rc;
+                if ((rc = judge_failed_launch(g, P->d_count.as<int32_t>(), P->d_Lmask.as<uint64_t>(), P->d_err.as<int8_t>(), P->d_synd.as<int8_t>(),
+                                              P->d_dec.as<int8_t>(), P->d_tally.as<unsigned long long>(), s)) != QLDPC_OK)
+                    return rc;
+            }
+            continue;
+        }
         const int64_t nq = (n + 3) / 4;
         if (B * nq > 0)
             hipLaunchKernelGGL(cc_sample_kernel, dim3((unsigned)((B * nq + 255) / 256)), dim3(256), 0, s, B, shot_begin + off,
@@ -199,7 +227,7 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
         {
             std::lock_guard<std::mutex> lk(g->mu);
             rc = minsum_decode_dispatch(g, B, P->d_synd.as<int8_t>(), P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(),
-                                        P->damping, P->clip, P->flags, P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
+                                        P->damping, P->clip, P->flags, P->nanfree, P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
                                         P->d_conv.as<uint8_t>(), P->d_iter.as<int32_t>(), s);
         }
         if (rc != QLDPC_OK) return rc;

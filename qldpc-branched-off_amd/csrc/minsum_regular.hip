@@ -1,0 +1,422 @@
+// Branch-free LDS/register-resident min-sum kernel for REGULAR Tanner graphs (every check of degree CDEG, every
+// variable of degree VDEG -- all bivariate-bicycle codes: CDEG = 6, VDEG = 3), optionally fused with the whole
+// code-capacity Monte-Carlo step.
+//
+// Thread mapping as in minsum_resident.hip (a team of TS threads owns one shot; a thread is the CHECK thread of one
+// row -- its check->variable messages R stay in registers for the whole decode -- and the VARIABLE thread of two
+// columns), but with compile-time degrees the check update is straight-line code:
+//   * Q = clip(V[col] - R) as v_min_f64/v_max_f64 (the NaN test of kernels.py:328 is kept unless the launcher proved
+//     that no NaN can arise: finite prior/clip/alpha and every check degree >= 2);
+//   * min1 = min-tree, argmin = FIRST lane of the equality mask (the reference's strict '<' keeps the first minimum,
+//     kernels.py:301-304), min2 = min-tree with that entry masked to +inf (duplicates of min1 therefore count,
+//     kernels.py:305-306);
+//   * signs are boolean masks (x < 0; note -0.0 counts as >= 0 exactly like `val >= 0`, kernels.py:296), the message is
+//     (+-alpha) * mag, one rounding, equal to the reference's (alpha * sign) * mag.
+// MC = true fuses the sampler (Philox4x32-10 stream of mc_common.h), the GF(2) syndrome (a6), the decode, the logical
+// comparison L (e xor e_hat) (engine.py:99-100) and the tally (engine.py:450-457) into the same launch: errors and
+// syndromes live in LDS, the posterior in registers; only shots BP fails on are written out (for the OSD-0 stage).
+#include "common.h"
+#include "mc_common.h"
+#include "minsum_common.h"
+
+#include <cstdlib>
+
+namespace qldpc {
+
+struct RegArgs {
+    int m, n, max_iter, fixed, S, TS;
+    const int32_t *indptr, *indices, *colptr, *rowidx, *csc2csr;
+    int64_t B;
+    const double *prior, *alpha;
+    double damping, clip;
+    // decode mode
+    const int8_t *synd; int8_t *out_err; double *out_llr; uint8_t *out_conv; int32_t *out_iter;
+    // Monte-Carlo mode
+    uint32_t seed_lo, seed_hi, thr; int use_osd;
+    int64_t shot_begin;
+    const uint64_t *Lmask;
+    unsigned long long *tally;
+    int32_t *fail_count, *fail_list; int8_t *f_synd, *f_err, *f_hard; double *f_llr;
+    // LDS carve (byte offsets)
+    int offV, offE, offL, offI;
+};
+
+__device__ __forceinline__ double min_tree6(const double *a) { return fmin(fmin(fmin(a[0], a[1]), fmin(a[2], a[3])), fmin(a[4], a[5])); }
+template <int D> __device__ __forceinline__ double min_tree(const double *a) {
+    double r = a[0];
+#pragma unroll
+    for (int k = 1; k < D; k++) r = fmin(r, a[k]);
+    return r;
+}
+template <> __device__ __forceinline__ double min_tree<6>(const double *a) { return min_tree6(a); }
+
+template <int CDEG, int VDEG, bool DAMP, bool NANFREE, bool MC>
+__global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
+    extern __shared__ unsigned char lds[];
+    constexpr int RST = (CDEG % 2 == 0) ? CDEG + 1 : CDEG;
+    const int m = A.m, n = A.n, S = A.S, TS = A.TS, max_iter = A.max_iter;
+    const int nq = (n + 3) >> 2;
+    const int slot = threadIdx.x / TS, member = threadIdx.x - slot * TS;
+    const bool in_team = slot < S;
+    const int sl = in_team ? slot : 0;
+    double *Rl = reinterpret_cast<double *>(lds) + (size_t)sl * m * RST;
+    double *Vl = reinterpret_cast<double *>(lds + A.offV) + (size_t)sl * n;
+    uint32_t *El = reinterpret_cast<uint32_t *>(lds + A.offE) + (size_t)sl * nq;
+    unsigned long long *lacc = reinterpret_cast<unsigned long long *>(lds + A.offL) + sl;
+    int *I = reinterpret_cast<int *>(lds + A.offI);
+    int *unsat = I + 2 * sl;            // [2] by iteration parity
+    int *active = I + 2 * S;            // [0] active shots, [1] any failure to export
+    int *sres = I + 2 * S + 2 + 4 * sl; // conv, final_iter, nonzero syndrome, failure index
+    const double clip = A.clip, nclip = -A.clip, damping = A.damping, one_minus_d = 1.0 - A.damping;
+
+    // ---- per-thread graph slices (registers, loaded once) ----
+    const bool has_check = in_team && member < m;
+    int coff[CDEG];
+#pragma unroll
+    for (int k = 0; k < CDEG; k++) coff[k] = has_check ? A.indices[A.indptr[member] + k] : 0;
+    const int roff = has_check ? member * RST : 0;
+    bool has_var[2];
+    int vj[2], voff[2][VDEG];
+    double vprior[2];
+    uint64_t vL[2];
+#pragma unroll
+    for (int v = 0; v < 2; v++) {
+        const int j = member + v * TS;
+        has_var[v] = in_team && j < n;
+        vj[v] = has_var[v] ? j : 0;
+        vprior[v] = has_var[v] ? A.prior[j] : 0.0;
+        vL[v] = (MC && has_var[v]) ? A.Lmask[j] : 0ull;
+#pragma unroll
+        for (int d = 0; d < VDEG; d++) {
+            voff[v][d] = 0;
+            if (has_var[v]) {
+                const int k = A.colptr[j] + d, row = A.rowidx[k];
+                voff[v][d] = row * RST + (A.csc2csr[k] - A.indptr[row]);
+            }
+        }
+    }
+    unsigned long long t_trials = 0, t_err = 0, t_conv = 0, t_iters = 0, t_zero = 0, t_unsat = 0;   // threads < S (MC)
+
+    for (int64_t base = (int64_t)blockIdx.x * S; base < A.B; base += (int64_t)gridDim.x * S) {
+        const int64_t b = base + slot;
+        const bool valid = in_team && b < A.B;
+        bool csyn = false;
+        int ve[2] = {0, 0};
+        if (MC) {
+            // ---- sample e ~ Bernoulli(p)^n (4 bits per Philox block), s = H e ----
+            if (valid && member < nq) {
+                const uint64_t g = (uint64_t)(A.shot_begin + b);
+                uint32_t o[4];
+                philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)member, 0u, A.seed_lo, A.seed_hi, o);
+                uint32_t w = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (4 * member + t < n && o[t] < A.thr) w |= 1u << (8 * t);
+                El[member] = w;
+            }
+            if (in_team && member == 0) { sres[0] = 0; sres[1] = 0; sres[2] = 0; sres[3] = -1; *lacc = 0ull; }
+            if (threadIdx.x == 0) active[1] = 0;
+            __syncthreads();
+            const uint8_t *Eb = reinterpret_cast<const uint8_t *>(El);
+            if (valid && has_check) {
+                int s = 0;
+#pragma unroll
+                for (int k = 0; k < CDEG; k++) s ^= Eb[coff[k]];
+                csyn = s & 1;
+                if (csyn) sres[2] = 1;
+            }
+#pragma unroll
+            for (int v = 0; v < 2; v++) ve[v] = (valid && has_var[v]) ? Eb[vj[v]] : 0;
+        } else {
+            csyn = (valid && has_check) ? (A.synd[b * m + member] & 1) : false;
+        }
+        double Rprev[CDEG], Qold[CDEG], vval[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < CDEG; k++) { Rprev[k] = 0.0; Qold[k] = 0.0; }
+#pragma unroll
+        for (int v = 0; v < 2; v++) if (has_var[v]) Vl[vj[v]] = vprior[v];             // Q_{-1} = prior[col] (kernels.py:263-265)
+        if (in_team && member == 0) { unsat[0] = 0; unsat[1] = 0; }
+        if (threadIdx.x == 0) { const int64_t left = A.B - base; active[0] = (int)(left < S ? left : S); }
+        bool done = !valid;
+        __syncthreads();
+
+        for (int it = 0; it <= max_iter; it++) {
+            // ======== check phase: syndrome test of values_{it-1}, then R_it from Q_{it-1} ========
+            if ((A.fixed ? valid : !done) && has_check) {
+                double x[CDEG];
+                bool par = csyn;
+#pragma unroll
+                for (int k = 0; k < CDEG; k++) { x[k] = Vl[coff[k]]; par ^= (x[k] < 0.0); }   // kernels.py:349,356
+                if (it >= 1 && !done && par) unsat[it & 1] = 1;                               // kernels.py:357-359
+                if (it < max_iter) {
+                    const double alpha = A.alpha[it];
+                    if (it > 0) {
+#pragma unroll
+                        for (int k = 0; k < CDEG; k++) {
+                            double t = x[k] - Rprev[k];                                        // kernels.py:325
+                            if (!NANFREE) t = (t != t) ? 0.0 : t;                              // kernels.py:328-329
+                            t = fmax(fmin(t, clip), nclip);                                    // kernels.py:330-333
+                            if (DAMP) t = fmax(fmin(damping * t + one_minus_d * Qold[k], clip), nclip);   // kernels.py:336-342
+                            x[k] = t;
+                        }
+                    }
+                    double a[CDEG], bmask[CDEG];
+                    bool neg[CDEG], first[CDEG];
+                    bool sp = csyn;                                                            // sign of 1 - 2 s (kernels.py:252,289)
+#pragma unroll
+                    for (int k = 0; k < CDEG; k++) {
+                        if (DAMP) Qold[k] = x[k];
+                        neg[k] = NANFREE ? (x[k] < 0.0) : !(x[k] >= 0.0);                      // kernels.py:296-299
+                        sp ^= neg[k];
+                        a[k] = fabs(x[k]);
+                    }
+                    double min1 = min_tree<CDEG>(a);
+                    if (!NANFREE) min1 = fmin(min1, INFINITY);
+                    bool found = false;
+#pragma unroll
+                    for (int k = 0; k < CDEG; k++) {                                           // first position of the minimum (kernels.py:301-304)
+                        first[k] = !found && (a[k] == min1);
+                        found = found || first[k];
+                        bmask[k] = first[k] ? INFINITY : a[k];
+                    }
+                    double min2 = min_tree<CDEG>(bmask);                                       // kernels.py:305-306
+                    if (!NANFREE) min2 = fmin(min2, INFINITY);
+#pragma unroll
+                    for (int k = 0; k < CDEG; k++) {
+                        const double mag = first[k] ? min2 : min1;                             // kernels.py:313
+                        const double msg = ((sp ^ neg[k]) ? -alpha : alpha) * mag;             // kernels.py:311-314
+                        Rprev[k] = msg;
+                        Rl[roff + k] = msg;
+                    }
+                }
+            }
+            __syncthreads();
+            // ======== variable phase: freeze test, then values_it ========
+            if (valid && !done) {
+                const bool conv = (it >= 1) && (unsat[it & 1] == 0);                           // kernels.py:361-364
+                if (conv || it == max_iter) {
+                    done = true;
+                    if (MC) {
+                        const bool exportit = !conv && A.use_osd;
+                        if (!exportit) {
+                            unsigned long long lm = 0ull;
+#pragma unroll
+                            for (int v = 0; v < 2; v++)
+                                if (has_var[v] && ((ve[v] ^ ((it >= 1 && vval[v] < 0.0) ? 1 : 0)) & 1)) lm ^= vL[v];
+                            if (lm) atomicXor(lacc, lm);
+                        } else if (member == 0) {
+                            active[1] = 1;
+                        }
+                        if (member == 0) { sres[0] = conv ? 1 : 0; sres[1] = conv ? it - 1 : max_iter - 1; atomicSub(&active[0], 1); }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 2; v++)
+                            if (has_var[v]) {
+                                const double xo = (it >= 1) ? vval[v] : 0.0;
+                                A.out_llr[b * n + vj[v]] = xo;
+                                A.out_err[b * n + vj[v]] = (xo < 0.0) ? 1 : 0;                 // kernels.py:349
+                            }
+                        if (member == 0) {
+                            A.out_conv[b] = conv ? 1 : 0;
+                            A.out_iter[b] = conv ? it - 1 : max_iter - 1;                      // kernels.py:267,362
+                            atomicSub(&active[0], 1);
+                        }
+                    }
+                }
+            }
+            if (in_team && member == 0) unsat[(it + 1) & 1] = 0;
+            if (it < max_iter && (A.fixed ? valid : !done)) {
+#pragma unroll
+                for (int v = 0; v < 2; v++)
+                    if (has_var[v]) {
+                        double s = 0.0;                                                        // kernels.py:279
+#pragma unroll
+                        for (int d = 0; d < VDEG; d++) s += Rl[voff[v][d]];                    // kernels.py:316, ascending check order
+                        const double xv = s + vprior[v];                                       // kernels.py:320
+                        if (!(MC && done)) vval[v] = xv;                                       // MC keeps the frozen posterior for the export
+                        Vl[vj[v]] = xv;
+                    }
+            }
+            __syncthreads();
+            if (!A.fixed && active[0] == 0) break;
+        }
+        __syncthreads();
+        if (MC) {
+            if (active[1]) {                        // block-uniform: some shot needs OSD-0 -> export its record
+                if (valid && member == 0 && sres[0] == 0 && A.use_osd) {
+                    const int f = atomicAdd(A.fail_count, 1);
+                    sres[3] = f;
+                    A.fail_list[f] = f;
+                }
+                __syncthreads();
+                const int f = valid ? sres[3] : -1;
+                if (f >= 0) {
+                    if (has_check) A.f_synd[(int64_t)f * m + member] = csyn ? 1 : 0;
+#pragma unroll
+                    for (int v = 0; v < 2; v++)
+                        if (has_var[v]) {
+                            const double xo = (max_iter >= 1) ? vval[v] : 0.0;
+                            A.f_llr[(int64_t)f * n + vj[v]] = xo;
+                            A.f_hard[(int64_t)f * n + vj[v]] = (xo < 0.0) ? 1 : 0;
+                            A.f_err[(int64_t)f * n + vj[v]] = (int8_t)ve[v];
+                        }
+                }
+                __syncthreads();
+            }
+            if ((int)threadIdx.x < S && base + threadIdx.x < A.B) {
+                const int *r = I + 2 * S + 2 + 4 * threadIdx.x;
+                const unsigned long long lm = *(reinterpret_cast<unsigned long long *>(lds + A.offL) + threadIdx.x);
+                const bool exported = (r[0] == 0) && A.use_osd;
+                t_trials++; t_conv += r[0]; t_iters += r[1] + 1; t_zero += r[2] ? 0 : 1;
+                if (!exported) { t_err += lm ? 1 : 0; t_unsat += r[0] ? 0 : 1; }
+            }
+            __syncthreads();
+        }
+    }
+    if (MC && (int)threadIdx.x < S) {
+        if (t_trials) atomicAdd(&A.tally[QLDPC_TALLY_TRIALS], t_trials);
+        if (t_err) { atomicAdd(&A.tally[QLDPC_TALLY_Z_ERR], t_err); atomicAdd(&A.tally[QLDPC_TALLY_TOTAL_ERR], t_err); }
+        if (t_conv) atomicAdd(&A.tally[QLDPC_TALLY_BP_CONV_Z], t_conv);
+        if (t_iters) atomicAdd(&A.tally[QLDPC_TALLY_ITERS_Z], t_iters);
+        if (t_zero) atomicAdd(&A.tally[QLDPC_TALLY_ZERO_SYND_Z], t_zero);
+        if (t_unsat) atomicAdd(&A.tally[QLDPC_TALLY_UNSAT_Z], t_unsat);
+    }
+}
+
+// judge of the exported failures after OSD-0: logical error / unsat / OSD count (32 lanes per record, device-side count)
+__global__ __launch_bounds__(256) void cc_judge_failed_kernel(const int32_t *__restrict__ count, int m, int n,
+                                                              const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                              const uint64_t *__restrict__ Lmask, const int8_t *__restrict__ err,
+                                                              const int8_t *__restrict__ synd, const int8_t *__restrict__ dec,
+                                                              unsigned long long *__restrict__ tally) {
+    const int total = *count;
+    const int lane = threadIdx.x & 31;
+    unsigned long long nerr = 0, nbad = 0;
+    for (int64_t b = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); b < total; b += (int64_t)gridDim.x * 8) {
+        const int8_t *e = err + b * n, *d = dec + b * n, *s = synd + b * m;
+        uint64_t lm = 0;
+        for (int j = lane; j < n; j += 32)
+            if ((e[j] ^ d[j]) & 1) lm ^= Lmask[j];
+        int bad = 0;
+        for (int i = lane; i < m; i += 32) {
+            int p = 0;
+            for (int k = indptr[i]; k < indptr[i + 1]; k++) p ^= d[indices[k]];
+            bad |= ((p ^ s[i]) & 1);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) { lm ^= __shfl_xor(lm, off, 32); bad |= __shfl_xor(bad, off, 32); }
+        if (lane == 0) { nerr += lm ? 1 : 0; nbad += bad ? 1 : 0; }
+    }
+    if (lane == 0) {
+        if (nerr) { atomicAdd(&tally[QLDPC_TALLY_Z_ERR], nerr); atomicAdd(&tally[QLDPC_TALLY_TOTAL_ERR], nerr); }
+        if (nbad) atomicAdd(&tally[QLDPC_TALLY_UNSAT_Z], nbad);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && total) atomicAdd(&tally[QLDPC_TALLY_OSD_Z], (unsigned long long)total);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+struct RegPlan { int cdeg, vdeg, TS, S, offV, offE, offL, offI; size_t lds; unsigned block; };
+
+static bool plan_regular(const qldpc_graph *g, RegPlan &P) {
+    if (g->m <= 0 || g->n <= 0) return false;
+    const int cdeg = g->max_row_deg, vdeg = g->max_col_deg;
+    if (!((cdeg == 6 && vdeg == 3) || (cdeg == 4 && vdeg == 2) || (cdeg == 8 && vdeg == 4))) return false;
+    for (int i = 0; i < g->m; i++) if (g->indptr[i + 1] - g->indptr[i] != cdeg) return false;
+    for (int j = 0; j < g->n; j++) if (g->colptr[j + 1] - g->colptr[j] != vdeg) return false;
+    const int ts = std::max(g->m, (g->n + 1) / 2);
+    if (ts > 640) return false;
+    const int rst = (cdeg % 2 == 0) ? cdeg + 1 : cdeg;
+    const int nq = (g->n + 3) / 4;
+    int S = 640 / ts;
+    if (const char *ov = getenv("QLDPC_RES_S")) { const int v = atoi(ov); if (v >= 1 && v * ts <= 640) S = v; }
+    auto layout = [&](int s) {
+        P.offV = s * g->m * rst * 8;
+        P.offE = P.offV + s * g->n * 8;
+        P.offL = (P.offE + s * nq * 4 + 7) / 8 * 8;
+        P.offI = P.offL + s * 8;
+        P.lds = (size_t)P.offI + (size_t)(6 * s + 2) * 4 + 16;
+    };
+    layout(S);
+    while (S > 1 && P.lds > 64 * 1024) { S--; layout(S); }
+    if (P.lds > 150 * 1024) return false;
+    P.cdeg = cdeg; P.vdeg = vdeg; P.TS = ts; P.S = S;
+    P.block = (unsigned)round_up((int64_t)S * ts, 64);
+    return true;
+}
+
+bool regular_supported(const qldpc_graph *g, double clip) {
+    RegPlan P;
+    return clip >= 0.0 && plan_regular(g, P);
+}
+
+template <int CDEG, int VDEG, bool MC>
+static int launch_reg(const RegArgs &A, bool damp, bool nanfree, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
+    if (damp) {
+        if (MC) return QLDPC_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((minsum_regular_kernel<CDEG, VDEG, true, false, false>), dim3(grid), dim3(block), lds, stream, A);
+    } else if (nanfree) {
+        hipLaunchKernelGGL((minsum_regular_kernel<CDEG, VDEG, false, true, MC>), dim3(grid), dim3(block), lds, stream, A);
+    } else {
+        hipLaunchKernelGGL((minsum_regular_kernel<CDEG, VDEG, false, false, MC>), dim3(grid), dim3(block), lds, stream, A);
+    }
+    QLDPC_HIP_TRY(hipGetLastError());
+    return QLDPC_OK;
+}
+
+template <bool MC>
+static int dispatch_reg(const RegPlan &P, const RegArgs &A, bool damp, bool nanfree, unsigned grid, hipStream_t stream) {
+    if (P.cdeg == 6) return launch_reg<6, 3, MC>(A, damp, nanfree, grid, P.block, P.lds, stream);
+    if (P.cdeg == 4) return launch_reg<4, 2, MC>(A, damp, nanfree, grid, P.block, P.lds, stream);
+    return launch_reg<8, 4, MC>(A, damp, nanfree, grid, P.block, P.lds, stream);
+}
+
+static void fill_common(const qldpc_graph *g, const RegPlan &P, RegArgs &A, int64_t B, const double *d_prior, int max_iter,
+                        const double *d_alpha, double damping, double clip, int flags) {
+    A = RegArgs{};
+    A.m = g->m; A.n = g->n; A.max_iter = max_iter; A.fixed = (flags & QLDPC_FLAG_FIXED_ITERS) ? 1 : 0;
+    A.S = P.S; A.TS = P.TS;
+    A.indptr = g->d_indptr; A.indices = g->d_indices; A.colptr = g->d_colptr; A.rowidx = g->d_rowidx; A.csc2csr = g->d_csc2csr;
+    A.B = B; A.prior = d_prior; A.alpha = d_alpha; A.damping = damping; A.clip = clip;
+    A.offV = P.offV; A.offE = P.offE; A.offL = P.offL; A.offI = P.offI;
+}
+
+static unsigned persistent_grid(int64_t B, int S) {
+    const int64_t groups = (B + S - 1) / S;
+    const int64_t cap = 256 * 12;
+    return (unsigned)(groups < cap ? (groups > 0 ? groups : 1) : cap);
+}
+
+int minsum_regular_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
+                          const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
+                          uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
+    RegPlan P;
+    if (!plan_regular(g, P)) { set_error("graph is not regular (6,3)/(4,2)/(8,4)"); return QLDPC_ERR_UNSUPPORTED; }
+    RegArgs A;
+    fill_common(g, P, A, B, d_prior, max_iter, d_alpha, damping, clip, flags);
+    A.synd = d_synd; A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;
+    return dispatch_reg<false>(P, A, damping != 1.0, nanfree, persistent_grid(B, P.S), stream);
+}
+
+int mc_regular_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int max_iter, const double *d_alpha, double clip, int flags,
+                      bool nanfree, uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask,
+                      unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd, int8_t *f_err,
+                      int8_t *f_hard, double *f_llr, hipStream_t stream) {
+    RegPlan P;
+    if (!plan_regular(g, P)) { set_error("graph is not regular (6,3)/(4,2)/(8,4)"); return QLDPC_ERR_UNSUPPORTED; }
+    RegArgs A;
+    fill_common(g, P, A, B, d_prior, max_iter, d_alpha, 1.0, clip, flags);
+    A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32); A.thr = thr; A.use_osd = use_osd; A.shot_begin = shot_begin;
+    A.Lmask = d_Lmask; A.tally = d_tally; A.fail_count = d_fail_count; A.fail_list = d_fail_list;
+    A.f_synd = f_synd; A.f_err = f_err; A.f_hard = f_hard; A.f_llr = f_llr;
+    return dispatch_reg<true>(P, A, false, nanfree, persistent_grid(B, P.S), stream);
+}
+
+int judge_failed_launch(const qldpc_graph *g, const int32_t *d_count, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
+                        const int8_t *f_dec, unsigned long long *d_tally, hipStream_t stream) {
+    hipLaunchKernelGGL(cc_judge_failed_kernel, dim3(64), dim3(256), 0, stream, d_count, g->m, g->n, g->d_indptr, g->d_indices, d_Lmask, f_err,
+                       f_synd, f_dec, d_tally);
+    QLDPC_HIP_TRY(hipGetLastError());
+    return QLDPC_OK;
+}
+
+}  // namespace qldpc

@@ -19,6 +19,8 @@
 #include "common.h"
 #include "minsum_common.h"
 
+#include <cstdlib>
+
 namespace qldpc {
 
 struct ResidentArgs {
@@ -224,6 +226,10 @@ static bool plan_resident(const qldpc_graph *g, ResidentPlan &P) {
     const size_t lds_budget = 64 * 1024;   // two workgroups per CU
     while (S > 1 && (size_t)S * per_slot + 16 > lds_budget) S--;
     if (S < 1) return false;
+    if (const char *ov = getenv("QLDPC_RES_S")) {          // tuning override (experiments only)
+        const int v = atoi(ov);
+        if (v >= 1 && v * ts <= 1024 && (size_t)v * per_slot + 16 <= 150 * 1024) S = v;
+    }
     P.S = S;
     P.lds = (size_t)S * per_slot + 16;
     return true;

@@ -20,7 +20,7 @@ def L():
     return _lib
 
 
-KERNELS = {"resident": 0x20, "stream": 0x10}
+KERNELS = {"regular": 0x20, "generic": 0x20 | 0x40, "stream": 0x10}   # "regular" falls back to generic on irregular graphs
 VARIANT_KW = {
     "const": dict(alpha=0.8, alpha_mode="alvarado"),
     "damp": dict(alpha=1.0, alpha_mode="dynamical", damping=0.7),
@@ -42,7 +42,7 @@ def decode(L, graph, synd, prior, max_iter, flags, alpha=1.0, alpha_mode="dynami
     return L.minsum_decode_batch(graph, synd, prior, max_iter, alpha_mode, alpha, damping, clip_llr, flags)
 
 
-@pytest.mark.parametrize("kern", ["resident", "stream"])
+@pytest.mark.parametrize("kern", ["regular", "generic", "stream"])
 def test_steane_golden(L, golden, kern):
     g = golden("steane_minsum")
     graph = L.Graph(g["indptr"], g["indices"], 7)
@@ -55,7 +55,7 @@ def test_steane_golden(L, golden, kern):
     check(decode(L, graph, g["syndromes"], g["prior2"], mi, KERNELS[kern]), g, "p2")
 
 
-@pytest.mark.parametrize("kern", ["resident", "stream"])
+@pytest.mark.parametrize("kern", ["regular", "generic", "stream"])
 @pytest.mark.parametrize("tag", ["bb72", "bb144", "bb288"])
 def test_bb_golden(L, golden, tag, kern):
     g = golden(tag + "_minsum")
@@ -101,7 +101,7 @@ def test_circuit_level_golden(L, golden, oracle, tag):
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
 
 
-@pytest.mark.parametrize("kern", ["resident", "stream"])
+@pytest.mark.parametrize("kern", ["regular", "generic", "stream"])
 def test_random_batch_vs_oracle(L, oracle, kern):
     """4096 seeded shots per point, hard regime included; ragged batch size (not a multiple of any tile)."""
     from qldpc_amd.data import load_code
@@ -240,8 +240,14 @@ def test_code_capacity_tally_matches_oracle(L, oracle):
         ta = L.cc_sample_decode_tally(graph, c["Lx"], p, 20260206, 0, N // 3, max_iter=50)
         tb = L.cc_sample_decode_tally(graph, c["Lx"], p, 20260206, N // 3, N - N // 3, max_iter=50)
         assert np.array_equal(ta + tb, ref)
-        t2 = L.cc_sample_decode_tally(graph, c["Lx"], p, 20260206, 0, N, max_iter=50, flags=L.FLAG_FIXED_ITERS | L.FLAG_KERNEL_STREAM)
-        assert np.array_equal(t2, ref)
+        for fl in (L.FLAG_FIXED_ITERS | L.FLAG_KERNEL_STREAM, L.FLAG_MC_UNFUSED, L.FLAG_FIXED_ITERS, L.FLAG_MC_UNFUSED | L.FLAG_KERNEL_GENERIC):
+            t2 = L.cc_sample_decode_tally(graph, c["Lx"], p, 20260206, 0, N, max_iter=50, flags=fl)
+            assert np.array_equal(t2, ref), (tag, fl, t2.tolist(), ref.tolist())
+        # without OSD the BP failures are judged as they are (and counted unsatisfied)
+        r0 = oracle.cc_sample_decode_tally(ip, ix, n, c["Lx"], p, 20260206, 0, N, max_iter=50, use_osd=False, threads=0)
+        for fl in (0, L.FLAG_MC_UNFUSED):
+            t0 = L.cc_sample_decode_tally(graph, c["Lx"], p, 20260206, 0, N, max_iter=50, use_osd=False, flags=fl)
+            assert np.array_equal(t0, r0), (tag, fl, t0.tolist(), r0.tolist())
         assert ref[L.TALLY["unsat_z"]] == 0          # OSD-0 always reproduces a realisable syndrome
     assert ref[0] == 1000
 
