@@ -30,7 +30,7 @@ int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     const bool want_stream = flags & QLDPC_FLAG_KERNEL_STREAM;
     const bool want_res = flags & (QLDPC_FLAG_KERNEL_RESIDENT | QLDPC_FLAG_KERNEL_GENERIC);
     const bool can_res = resident_supported(g, damping);
-    if (!want_stream && !(flags & QLDPC_FLAG_KERNEL_GENERIC) && regular_supported(g, clip))
+    if (!want_stream && !(flags & QLDPC_FLAG_KERNEL_GENERIC) && regular_supported(g, clip, max_iter))
         return minsum_regular_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
     if (want_res && !can_res) {
         set_error("resident kernel does not support this graph (m=%d n=%d max row degree %d, max column degree %d)", g->m, g->n,

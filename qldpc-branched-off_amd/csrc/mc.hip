@@ -121,7 +121,7 @@ struct qldpc_cc_plan {
     uint32_t thr = 0;
     int64_t batch = 0;
     std::vector<double> alpha;
-    DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol;
+    DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol, d_cold;
     bool fused = false, nanfree = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decode-kernel brackets not yet read
@@ -165,7 +165,7 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
     P->nanfree = std::isfinite(clip_llr);
     for (double a : P->alpha) P->nanfree = P->nanfree && std::isfinite(a);
     P->fused = !(flags & (QLDPC_FLAG_MC_UNFUSED | QLDPC_FLAG_KERNEL_STREAM | QLDPC_FLAG_KERNEL_GENERIC)) && damping == 1.0 &&
-               regular_supported(g, clip_llr);
+               regular_supported(g, clip_llr, max_iter);
     if ((rc = P->d_alpha.ensure(P->alpha.size() * 8)) || (rc = P->d_prior.ensure(prior.size() * 8)) ||
         (rc = P->d_Lmask.ensure(Lmask.size() * 8)) || (rc = P->d_err.ensure(batch * n)) || (rc = P->d_synd.ensure(batch * m)) ||
         (rc = P->d_dec.ensure(batch * n)) || (rc = P->d_llr.ensure(batch * n * 8)) || (rc = P->d_conv.ensure(batch)) ||
@@ -178,6 +178,12 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
         hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8) != hipSuccess) {
         set_error("plan upload failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(QLDPC_ERR_HIP);
+    }
+    if (P->fused) {
+        if ((rc = P->d_cold.ensure(mc_regular_cold_bytes())) != QLDPC_OK) return fail(rc);
+        if ((rc = mc_regular_fill_cold(P->d_cold.p, P->d_tally.as<unsigned long long>(), P->d_count.as<int32_t>(), P->d_list.as<int32_t>(),
+                                       P->d_synd.as<int8_t>(), P->d_err.as<int8_t>(), P->d_dec.as<int8_t>(), P->d_llr.as<double>())) != QLDPC_OK)
+            return fail(rc);
     }
     *out = P;
     return QLDPC_OK;
@@ -200,9 +206,7 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
             hipEvent_t e0 = get_event(P), e1 = get_event(P);
             if (e0 && e1) QLDPC_HIP_TRY(hipEventRecord(e0, s));
             rc = mc_regular_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, P->nanfree, seed,
-                                   shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_tally.as<unsigned long long>(),
-                                   P->d_count.as<int32_t>(), P->d_list.as<int32_t>(), P->d_synd.as<int8_t>(), P->d_err.as<int8_t>(),
-                                   P->d_dec.as<int8_t>(), P->d_llr.as<double>(), s);
+                                   shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_cold.p, s);
             if (rc != QLDPC_OK) return rc;
             if (e0 && e1) { QLDPC_HIP_TRY(hipEventRecord(e1, s)); P->pending.emplace_back(e0, e1); }
             if (P->use_osd) {
@@ -290,7 +294,7 @@ QLDPC_EXPORT void qldpc_cc_plan_destroy(qldpc_cc_plan *P) {
     for (auto &pr : P->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : P->pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&P->d_alpha, &P->d_prior, &P->d_Lmask, &P->d_err, &P->d_synd, &P->d_dec, &P->d_llr, &P->d_conv, &P->d_iter,
-                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol})
+                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol, &P->d_cold})
         b->release();
     delete P;
 }

@@ -33,14 +33,16 @@ int minsum_resident_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd
                            uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
 bool resident_supported(const qldpc_graph *g, double damping);
 // regular-degree fast path (minsum_regular.hip).  nanfree: the caller proved prior / clip / alphas finite.
-bool regular_supported(const qldpc_graph *g, double clip);
+bool regular_supported(const qldpc_graph *g, double clip, int max_iter);
 int minsum_regular_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
                           const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
 int mc_regular_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int max_iter, const double *d_alpha, double clip, int flags,
                       bool nanfree, uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask,
-                      unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd, int8_t *f_err,
-                      int8_t *f_hard, double *f_llr, hipStream_t stream);
+                      void *d_cold, hipStream_t stream);
+int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd,
+                         int8_t *f_err, int8_t *f_hard, double *f_llr);
+size_t mc_regular_cold_bytes();
 int judge_failed_launch(const qldpc_graph *g, const int32_t *d_count, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
                         const int8_t *f_dec, unsigned long long *d_tally, hipStream_t stream);
 int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,

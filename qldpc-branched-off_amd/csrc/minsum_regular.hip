@@ -35,11 +35,39 @@ struct RegArgs {
     uint32_t seed_lo, seed_hi, thr; int use_osd;
     int64_t shot_begin;
     const uint64_t *Lmask;
+    const struct RegCold *cold;     // rarely used pointers live in device memory to keep scalar registers free
+    // LDS carve (byte offsets)
+    int offV, offE, offL, offI, offA, offT;
+    int exp;                        // QLDPC_EXP timing experiments (0 in production)
+};
+
+struct RegCold {
     unsigned long long *tally;
     int32_t *fail_count, *fail_list; int8_t *f_synd, *f_err, *f_hard; double *f_llr;
-    // LDS carve (byte offsets)
-    int offV, offE, offL, offI;
 };
+
+// v_min_f64 / v_max_f64 without the canonicalising v_max the compiler adds around fmin()/fmax() (operands here are
+// results of arithmetic or LDS loads of such results; for NaN operands the instructions return the other operand).
+__device__ __forceinline__ double vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmin_abs(double a, double b) { double r; asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmax_abs(double a, double b) { double r; asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// The two smallest magnitudes (with multiplicity) of x[0..D): pairs -> (min,max), then merge (lo,hi) sets:
+// lo = min(l1,l2), hi = min(max(l1,l2), min(h1,h2)).  min1/min2 of kernels.py:301-306 are exactly these values.
+template <int D>
+__device__ __forceinline__ void two_smallest_abs(const double *x, double &lo, double &hi) {
+    static_assert(D % 2 == 0 && D >= 2, "even degree");
+    lo = vmin_abs(x[0], x[1]);
+    hi = vmax_abs(x[0], x[1]);
+#pragma unroll
+    for (int k = 2; k < D; k += 2) {
+        const double l2 = vmin_abs(x[k], x[k + 1]), h2 = vmax_abs(x[k], x[k + 1]);
+        const double nlo = vmin(lo, l2);
+        hi = vmin(vmax(lo, l2), vmin(hi, h2));
+        lo = nlo;
+    }
+}
 
 __device__ __forceinline__ double min_tree6(const double *a) { return fmin(fmin(fmin(a[0], a[1]), fmin(a[2], a[3])), fmin(a[4], a[5])); }
 template <int D> __device__ __forceinline__ double min_tree(const double *a) {
@@ -50,8 +78,12 @@ template <int D> __device__ __forceinline__ double min_tree(const double *a) {
 }
 template <> __device__ __forceinline__ double min_tree<6>(const double *a) { return min_tree6(a); }
 
+#ifndef QLDPC_LB_T
+#define QLDPC_LB_T 512
+#define QLDPC_LB_W 8
+#endif
 template <int CDEG, int VDEG, bool DAMP, bool NANFREE, bool MC>
-__global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
+__global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(RegArgs A) {
     extern __shared__ unsigned char lds[];
     constexpr int RST = (CDEG % 2 == 0) ? CDEG + 1 : CDEG;
     const int m = A.m, n = A.n, S = A.S, TS = A.TS, max_iter = A.max_iter;
@@ -67,7 +99,11 @@ __global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
     int *unsat = I + 2 * sl;            // [2] by iteration parity
     int *active = I + 2 * S;            // [0] active shots, [1] any failure to export
     int *sres = I + 2 * S + 2 + 4 * sl; // conv, final_iter, nonzero syndrome, failure index
+    const double *Al = reinterpret_cast<const double *>(lds + A.offA);                  // alpha_k staged in LDS
+    unsigned long long *Tl = reinterpret_cast<unsigned long long *>(lds + A.offT);      // block tally (MC)
     const double clip = A.clip, nclip = -A.clip, damping = A.damping, one_minus_d = 1.0 - A.damping;
+    for (int k = threadIdx.x; k < max_iter; k += blockDim.x) reinterpret_cast<double *>(lds + A.offA)[k] = A.alpha[k];
+    if (MC && threadIdx.x < 6) Tl[threadIdx.x] = 0ull;
 
     // ---- per-thread graph slices (registers, loaded once) ----
     const bool has_check = in_team && member < m;
@@ -78,14 +114,12 @@ __global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
     bool has_var[2];
     int vj[2], voff[2][VDEG];
     double vprior[2];
-    uint64_t vL[2];
 #pragma unroll
     for (int v = 0; v < 2; v++) {
         const int j = member + v * TS;
         has_var[v] = in_team && j < n;
         vj[v] = has_var[v] ? j : 0;
         vprior[v] = has_var[v] ? A.prior[j] : 0.0;
-        vL[v] = (MC && has_var[v]) ? A.Lmask[j] : 0ull;
 #pragma unroll
         for (int d = 0; d < VDEG; d++) {
             voff[v][d] = 0;
@@ -95,13 +129,11 @@ __global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
             }
         }
     }
-    unsigned long long t_trials = 0, t_err = 0, t_conv = 0, t_iters = 0, t_zero = 0, t_unsat = 0;   // threads < S (MC)
 
     for (int64_t base = (int64_t)blockIdx.x * S; base < A.B; base += (int64_t)gridDim.x * S) {
         const int64_t b = base + slot;
         const bool valid = in_team && b < A.B;
         bool csyn = false;
-        int ve[2] = {0, 0};
         if (MC) {
             // ---- sample e ~ Bernoulli(p)^n (4 bits per Philox block), s = H e ----
             if (valid && member < nq) {
@@ -125,12 +157,10 @@ __global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
                 csyn = s & 1;
                 if (csyn) sres[2] = 1;
             }
-#pragma unroll
-            for (int v = 0; v < 2; v++) ve[v] = (valid && has_var[v]) ? Eb[vj[v]] : 0;
         } else {
             csyn = (valid && has_check) ? (A.synd[b * m + member] & 1) : false;
         }
-        double Rprev[CDEG], Qold[CDEG], vval[2] = {0.0, 0.0};
+        double Rprev[CDEG], Qold[CDEG];
 #pragma unroll
         for (int k = 0; k < CDEG; k++) { Rprev[k] = 0.0; Qold[k] = 0.0; }
 #pragma unroll
@@ -149,48 +179,52 @@ __global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
                 for (int k = 0; k < CDEG; k++) { x[k] = Vl[coff[k]]; par ^= (x[k] < 0.0); }   // kernels.py:349,356
                 if (it >= 1 && !done && par) unsat[it & 1] = 1;                               // kernels.py:357-359
                 if (it < max_iter) {
-                    const double alpha = A.alpha[it];
+                    const double alpha = Al[it];
                     if (it > 0) {
 #pragma unroll
                         for (int k = 0; k < CDEG; k++) {
                             double t = x[k] - Rprev[k];                                        // kernels.py:325
                             if (!NANFREE) t = (t != t) ? 0.0 : t;                              // kernels.py:328-329
-                            t = fmax(fmin(t, clip), nclip);                                    // kernels.py:330-333
-                            if (DAMP) t = fmax(fmin(damping * t + one_minus_d * Qold[k], clip), nclip);   // kernels.py:336-342
+                            t = vmax(vmin(t, clip), nclip);                                    // kernels.py:330-333
+                            if (DAMP) t = vmax(vmin(damping * t + one_minus_d * Qold[k], clip), nclip);   // kernels.py:336-342
                             x[k] = t;
                         }
                     }
-                    double a[CDEG], bmask[CDEG];
-                    bool neg[CDEG], first[CDEG];
+                    bool neg[CDEG];
                     bool sp = csyn;                                                            // sign of 1 - 2 s (kernels.py:252,289)
 #pragma unroll
                     for (int k = 0; k < CDEG; k++) {
                         if (DAMP) Qold[k] = x[k];
-                        neg[k] = NANFREE ? (x[k] < 0.0) : !(x[k] >= 0.0);                      // kernels.py:296-299
+                        neg[k] = NANFREE ? (x[k] < 0.0) : !(x[k] >= 0.0);                      // kernels.py:296-299 (-0.0 counts as >= 0)
                         sp ^= neg[k];
-                        a[k] = fabs(x[k]);
                     }
-                    double min1 = min_tree<CDEG>(a);
-                    if (!NANFREE) min1 = fmin(min1, INFINITY);
-                    bool found = false;
+                    double min1, min2;
+                    if (NANFREE) {
+                        two_smallest_abs<CDEG>(x, min1, min2);                                 // kernels.py:301-306
+                    } else {                                   // NaN-tolerant form: NaN magnitudes are ignored like `abs_val < min1`
+                        min1 = INFINITY; min2 = INFINITY;
 #pragma unroll
-                    for (int k = 0; k < CDEG; k++) {                                           // first position of the minimum (kernels.py:301-304)
-                        first[k] = !found && (a[k] == min1);
-                        found = found || first[k];
-                        bmask[k] = first[k] ? INFINITY : a[k];
+                        for (int k = 0; k < CDEG; k++) {
+                            const double a = fabs(x[k]);
+                            if (a < min1) { min2 = min1; min1 = a; } else if (a < min2) { min2 = a; }
+                        }
                     }
-                    double min2 = min_tree<CDEG>(bmask);                                       // kernels.py:305-306
-                    if (!NANFREE) min2 = fmin(min2, INFINITY);
+                    // the first minimum gets min2, everybody else min1 (kernels.py:313).  If the minimum is attained twice,
+                    // min2 == min1, so selecting on |q| == min1 gives the same value at every position.
+                    const double p1 = alpha * min1, p2 = alpha * min2;                         // (+-alpha)*mag == +-(alpha*mag)
+                    const int p1lo = __double2loint(p1), p1hi = __double2hiint(p1), p2lo = __double2loint(p2), p2hi = __double2hiint(p2);
 #pragma unroll
                     for (int k = 0; k < CDEG; k++) {
-                        const double mag = first[k] ? min2 : min1;                             // kernels.py:313
-                        const double msg = ((sp ^ neg[k]) ? -alpha : alpha) * mag;             // kernels.py:311-314
+                        const bool eq = (fabs(x[k]) == min1);
+                        const int lo = eq ? p2lo : p1lo;
+                        const int hi = (eq ? p2hi : p1hi) ^ ((sp != neg[k]) ? (int)0x80000000 : 0);   // kernels.py:311-314
+                        const double msg = __hiloint2double(hi, lo);
                         Rprev[k] = msg;
-                        Rl[roff + k] = msg;
+                        if (!(A.exp & 2)) Rl[roff + k] = msg;
                     }
                 }
             }
-            __syncthreads();
+            if (!(A.exp & 1)) __syncthreads();
             // ======== variable phase: freeze test, then values_it ========
             if (valid && !done) {
                 const bool conv = (it >= 1) && (unsat[it & 1] == 0);                           // kernels.py:361-364
@@ -199,10 +233,11 @@ __global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
                     if (MC) {
                         const bool exportit = !conv && A.use_osd;
                         if (!exportit) {
+                            const uint8_t *Eb = reinterpret_cast<const uint8_t *>(El);
                             unsigned long long lm = 0ull;
 #pragma unroll
                             for (int v = 0; v < 2; v++)
-                                if (has_var[v] && ((ve[v] ^ ((it >= 1 && vval[v] < 0.0) ? 1 : 0)) & 1)) lm ^= vL[v];
+                                if (has_var[v] && ((Eb[vj[v]] ^ ((it >= 1 && Vl[vj[v]] < 0.0) ? 1 : 0)) & 1)) lm ^= A.Lmask[vj[v]];   // V still holds values_{it-1}
                             if (lm) atomicXor(lacc, lm);
                         } else if (member == 0) {
                             active[1] = 1;
@@ -212,7 +247,7 @@ __global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
 #pragma unroll
                         for (int v = 0; v < 2; v++)
                             if (has_var[v]) {
-                                const double xo = (it >= 1) ? vval[v] : 0.0;
+                                const double xo = (it >= 1) ? Vl[vj[v]] : 0.0;        // V still holds values_{it-1}
                                 A.out_llr[b * n + vj[v]] = xo;
                                 A.out_err[b * n + vj[v]] = (xo < 0.0) ? 1 : 0;                 // kernels.py:349
                             }
@@ -233,32 +268,33 @@ __global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
 #pragma unroll
                         for (int d = 0; d < VDEG; d++) s += Rl[voff[v][d]];                    // kernels.py:316, ascending check order
                         const double xv = s + vprior[v];                                       // kernels.py:320
-                        if (!(MC && done)) vval[v] = xv;                                       // MC keeps the frozen posterior for the export
-                        Vl[vj[v]] = xv;
+                        if (!(A.exp & 2)) Vl[vj[v]] = xv;
                     }
             }
-            __syncthreads();
+            if (!(A.exp & 1)) __syncthreads();
             if (!A.fixed && active[0] == 0) break;
         }
         __syncthreads();
         if (MC) {
             if (active[1]) {                        // block-uniform: some shot needs OSD-0 -> export its record
+                const RegCold C = *A.cold;
                 if (valid && member == 0 && sres[0] == 0 && A.use_osd) {
-                    const int f = atomicAdd(A.fail_count, 1);
+                    const int f = atomicAdd(C.fail_count, 1);
                     sres[3] = f;
-                    A.fail_list[f] = f;
+                    C.fail_list[f] = f;
                 }
                 __syncthreads();
                 const int f = valid ? sres[3] : -1;
                 if (f >= 0) {
-                    if (has_check) A.f_synd[(int64_t)f * m + member] = csyn ? 1 : 0;
+                    const uint8_t *Eb = reinterpret_cast<const uint8_t *>(El);
+                    if (has_check) C.f_synd[(int64_t)f * m + member] = csyn ? 1 : 0;
 #pragma unroll
                     for (int v = 0; v < 2; v++)
                         if (has_var[v]) {
-                            const double xo = (max_iter >= 1) ? vval[v] : 0.0;
-                            A.f_llr[(int64_t)f * n + vj[v]] = xo;
-                            A.f_hard[(int64_t)f * n + vj[v]] = (xo < 0.0) ? 1 : 0;
-                            A.f_err[(int64_t)f * n + vj[v]] = (int8_t)ve[v];
+                            const double xo = (max_iter >= 1) ? Vl[vj[v]] : 0.0;
+                            C.f_llr[(int64_t)f * n + vj[v]] = xo;
+                            C.f_hard[(int64_t)f * n + vj[v]] = (xo < 0.0) ? 1 : 0;
+                            C.f_err[(int64_t)f * n + vj[v]] = (int8_t)Eb[vj[v]];
                         }
                 }
                 __syncthreads();
@@ -267,19 +303,21 @@ __global__ __launch_bounds__(640) void minsum_regular_kernel(RegArgs A) {
                 const int *r = I + 2 * S + 2 + 4 * threadIdx.x;
                 const unsigned long long lm = *(reinterpret_cast<unsigned long long *>(lds + A.offL) + threadIdx.x);
                 const bool exported = (r[0] == 0) && A.use_osd;
-                t_trials++; t_conv += r[0]; t_iters += r[1] + 1; t_zero += r[2] ? 0 : 1;
-                if (!exported) { t_err += lm ? 1 : 0; t_unsat += r[0] ? 0 : 1; }
+                atomicAdd(&Tl[0], 1ull);
+                if (r[0]) atomicAdd(&Tl[2], 1ull);
+                atomicAdd(&Tl[3], (unsigned long long)(r[1] + 1));
+                if (!r[2]) atomicAdd(&Tl[4], 1ull);
+                if (!exported) { if (lm) atomicAdd(&Tl[1], 1ull); if (!r[0]) atomicAdd(&Tl[5], 1ull); }
             }
             __syncthreads();
         }
     }
-    if (MC && (int)threadIdx.x < S) {
-        if (t_trials) atomicAdd(&A.tally[QLDPC_TALLY_TRIALS], t_trials);
-        if (t_err) { atomicAdd(&A.tally[QLDPC_TALLY_Z_ERR], t_err); atomicAdd(&A.tally[QLDPC_TALLY_TOTAL_ERR], t_err); }
-        if (t_conv) atomicAdd(&A.tally[QLDPC_TALLY_BP_CONV_Z], t_conv);
-        if (t_iters) atomicAdd(&A.tally[QLDPC_TALLY_ITERS_Z], t_iters);
-        if (t_zero) atomicAdd(&A.tally[QLDPC_TALLY_ZERO_SYND_Z], t_zero);
-        if (t_unsat) atomicAdd(&A.tally[QLDPC_TALLY_UNSAT_Z], t_unsat);
+    if (MC && threadIdx.x < 6 && Tl[threadIdx.x]) {
+        unsigned long long *tally = A.cold->tally;
+        const unsigned long long v = Tl[threadIdx.x];
+        const int slotmap[6] = {QLDPC_TALLY_TRIALS, QLDPC_TALLY_Z_ERR, QLDPC_TALLY_BP_CONV_Z, QLDPC_TALLY_ITERS_Z, QLDPC_TALLY_ZERO_SYND_Z, QLDPC_TALLY_UNSAT_Z};
+        atomicAdd(&tally[slotmap[threadIdx.x]], v);
+        if (threadIdx.x == 1) atomicAdd(&tally[QLDPC_TALLY_TOTAL_ERR], v);
     }
 }
 
@@ -315,38 +353,41 @@ __global__ __launch_bounds__(256) void cc_judge_failed_kernel(const int32_t *__r
 }
 
 // ------------------------------------------------------------------------------------------ host side
-struct RegPlan { int cdeg, vdeg, TS, S, offV, offE, offL, offI; size_t lds; unsigned block; };
+struct RegPlan { int cdeg, vdeg, TS, S, offV, offE, offL, offI, offA, offT; size_t lds; unsigned block; };
+static const int kMaxIterLds = 1024;
 
-static bool plan_regular(const qldpc_graph *g, RegPlan &P) {
-    if (g->m <= 0 || g->n <= 0) return false;
+static bool plan_regular(const qldpc_graph *g, int max_iter, RegPlan &P) {
+    if (g->m <= 0 || g->n <= 0 || max_iter > kMaxIterLds) return false;
     const int cdeg = g->max_row_deg, vdeg = g->max_col_deg;
     if (!((cdeg == 6 && vdeg == 3) || (cdeg == 4 && vdeg == 2) || (cdeg == 8 && vdeg == 4))) return false;
     for (int i = 0; i < g->m; i++) if (g->indptr[i + 1] - g->indptr[i] != cdeg) return false;
     for (int j = 0; j < g->n; j++) if (g->colptr[j + 1] - g->colptr[j] != vdeg) return false;
     const int ts = std::max(g->m, (g->n + 1) / 2);
-    if (ts > 640) return false;
+    if (ts > QLDPC_LB_T) return false;
     const int rst = (cdeg % 2 == 0) ? cdeg + 1 : cdeg;
     const int nq = (g->n + 3) / 4;
-    int S = 640 / ts;
-    if (const char *ov = getenv("QLDPC_RES_S")) { const int v = atoi(ov); if (v >= 1 && v * ts <= 640) S = v; }
+    int S = QLDPC_LB_T / ts;                           // 4 blocks per CU fill its 32 wave slots
+    if (const char *ov = getenv("QLDPC_RES_S")) { const int v = atoi(ov); if (v >= 1 && v * ts <= QLDPC_LB_T) S = v; }
     auto layout = [&](int s) {
         P.offV = s * g->m * rst * 8;
         P.offE = P.offV + s * g->n * 8;
         P.offL = (P.offE + s * nq * 4 + 7) / 8 * 8;
         P.offI = P.offL + s * 8;
-        P.lds = (size_t)P.offI + (size_t)(6 * s + 2) * 4 + 16;
+        P.offA = (P.offI + (6 * s + 2) * 4 + 7) / 8 * 8;
+        P.offT = P.offA + (max_iter > 0 ? max_iter : 1) * 8;
+        P.lds = (size_t)P.offT + 6 * 8 + 16;
     };
     layout(S);
-    while (S > 1 && P.lds > 64 * 1024) { S--; layout(S); }
+    while (S > 1 && P.lds > 39 * 1024) { S--; layout(S); }      // 4 blocks per CU within 160 KiB
     if (P.lds > 150 * 1024) return false;
     P.cdeg = cdeg; P.vdeg = vdeg; P.TS = ts; P.S = S;
     P.block = (unsigned)round_up((int64_t)S * ts, 64);
     return true;
 }
 
-bool regular_supported(const qldpc_graph *g, double clip) {
+bool regular_supported(const qldpc_graph *g, double clip, int max_iter) {
     RegPlan P;
-    return clip >= 0.0 && plan_regular(g, P);
+    return clip >= 0.0 && plan_regular(g, max_iter, P);
 }
 
 template <int CDEG, int VDEG, bool MC>
@@ -377,7 +418,8 @@ static void fill_common(const qldpc_graph *g, const RegPlan &P, RegArgs &A, int6
     A.S = P.S; A.TS = P.TS;
     A.indptr = g->d_indptr; A.indices = g->d_indices; A.colptr = g->d_colptr; A.rowidx = g->d_rowidx; A.csc2csr = g->d_csc2csr;
     A.B = B; A.prior = d_prior; A.alpha = d_alpha; A.damping = damping; A.clip = clip;
-    A.offV = P.offV; A.offE = P.offE; A.offL = P.offL; A.offI = P.offI;
+    if (const char *e = getenv("QLDPC_EXP")) A.exp = atoi(e);
+    A.offV = P.offV; A.offE = P.offE; A.offL = P.offL; A.offI = P.offI; A.offA = P.offA; A.offT = P.offT;
 }
 
 static unsigned persistent_grid(int64_t B, int S) {
@@ -390,7 +432,7 @@ int minsum_regular_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd,
                           const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
     RegPlan P;
-    if (!plan_regular(g, P)) { set_error("graph is not regular (6,3)/(4,2)/(8,4)"); return QLDPC_ERR_UNSUPPORTED; }
+    if (!plan_regular(g, max_iter, P)) { set_error("graph is not regular (6,3)/(4,2)/(8,4)"); return QLDPC_ERR_UNSUPPORTED; }
     RegArgs A;
     fill_common(g, P, A, B, d_prior, max_iter, d_alpha, damping, clip, flags);
     A.synd = d_synd; A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;
@@ -399,17 +441,24 @@ int minsum_regular_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd,
 
 int mc_regular_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int max_iter, const double *d_alpha, double clip, int flags,
                       bool nanfree, uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask,
-                      unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd, int8_t *f_err,
-                      int8_t *f_hard, double *f_llr, hipStream_t stream) {
+                      void *d_cold, hipStream_t stream) {
     RegPlan P;
-    if (!plan_regular(g, P)) { set_error("graph is not regular (6,3)/(4,2)/(8,4)"); return QLDPC_ERR_UNSUPPORTED; }
+    if (!plan_regular(g, max_iter, P)) { set_error("graph is not regular (6,3)/(4,2)/(8,4)"); return QLDPC_ERR_UNSUPPORTED; }
     RegArgs A;
     fill_common(g, P, A, B, d_prior, max_iter, d_alpha, 1.0, clip, flags);
     A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32); A.thr = thr; A.use_osd = use_osd; A.shot_begin = shot_begin;
-    A.Lmask = d_Lmask; A.tally = d_tally; A.fail_count = d_fail_count; A.fail_list = d_fail_list;
-    A.f_synd = f_synd; A.f_err = f_err; A.f_hard = f_hard; A.f_llr = f_llr;
+    A.Lmask = d_Lmask; A.cold = reinterpret_cast<const RegCold *>(d_cold);
     return dispatch_reg<true>(P, A, false, nanfree, persistent_grid(B, P.S), stream);
 }
+
+// Fills the device-resident cold-argument block of a Monte-Carlo plan (done once per plan).
+int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd,
+                         int8_t *f_err, int8_t *f_hard, double *f_llr) {
+    RegCold C{d_tally, d_fail_count, d_fail_list, f_synd, f_err, f_hard, f_llr};
+    QLDPC_HIP_TRY(hipMemcpy(d_cold, &C, sizeof(C), hipMemcpyHostToDevice));
+    return QLDPC_OK;
+}
+size_t mc_regular_cold_bytes() { return sizeof(RegCold); }
 
 int judge_failed_launch(const qldpc_graph *g, const int32_t *d_count, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
                         const int8_t *f_dec, unsigned long long *d_tally, hipStream_t stream) {
