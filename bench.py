@@ -112,16 +112,26 @@ def main():
     bytes_fixed = args.max_iter * 16 * nnz + b_io
     bytes_ref = mean_iters * 16 * nnz + b_io
 
-    def roof(bytes_per_shot, ms, launches):
+    traffic = {}
+    try:      # HBM bytes per launch measured separately with rocprofv3 PMC passes on this exact configuration
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            tj = json.load(fh)
+        if tj.get("code") == args.code and tj.get("batch") == B and args.kernel == "auto":
+            traffic = tj["bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
+    def roof(bytes_per_shot, ms, launches, mode):
         if launches <= 0 or ms <= 0:
             return None
         per_launch_ms = ms / launches
         ach = bytes_per_shot * B / (per_launch_ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel_ms_per_launch": round(per_launch_ms, 4), "launches": int(launches),
+                "traffic": traffic.get(mode), "kernel_ms_per_launch": round(per_launch_ms, 4), "launches": int(launches),
                 "algorithmic_bytes_per_shot": round(float(bytes_per_shot), 1),
-                "note": "algorithmic bytes/s of the streaming message-passing model; messages are register/LDS resident, "
-                        "so this is NOT measured HBM traffic (see profiles/ for PMC FETCH_SIZE/WRITE_SIZE)"}
+                "traffic_unit": "bytes per launch (PMC 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.txt)",
+                "note": "achieved = algorithmic bytes of the streaming message-passing model / kernel time; the messages are "
+                        "register/LDS resident, so `traffic` (measured HBM bytes) is ~0.04% of it and frac > 1 means HBM is not the bound"}
 
     out = {
         "metric": "decoded shots/sec, [[144,12,12]] p=0.005 50 BP iters",
@@ -132,9 +142,9 @@ def main():
                                f"dynamic alpha, OSD-0 on BP failures, batch={B} shots/step/GPU, fixed-work mode (all {args.max_iter} "
                                "iterations executed per shot, outputs frozen at convergence)",
                    "code": args.code, "batch": B, "mode": "fixed_iters", "kernel": args.kernel, "seed": SEED},
-        "roofline": roof(bytes_fixed, ms_fixed, nl_fixed),
+        "roofline": roof(bytes_fixed, ms_fixed, nl_fixed, "fixed_iters"),
         "reference_semantics": {"value": round(shots_total / dt_ref, 1), "unit": "shots/s", "ms_per_step": round(dt_ref / K * 1e3, 4),
-                                "mean_iterations": round(float(mean_iters), 4), "roofline": roof(bytes_ref, ms_ref, nl_ref)},
+                                "mean_iterations": round(float(mean_iters), 4), "roofline": roof(bytes_ref, ms_ref, nl_ref, "reference_semantics")},
         "tally": {k: int(tally_ref[v]) for k, v in T.items() if k.endswith("_z") or k in ("trials", "total_err")},
     }
 
