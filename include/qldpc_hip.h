@@ -162,6 +162,36 @@ int qldpc_cc_plan_read(qldpc_cc_plan *plan, void *stream, int clear, int64_t *ta
 int qldpc_cc_plan_kernel_time(qldpc_cc_plan *plan, double *ms_total, int64_t *launches);
 void qldpc_cc_plan_destroy(qldpc_cc_plan *plan);
 
+/* ---- circuit-level Monte-Carlo (BASELINE config 5) ------------------------------------------------------------
+ * Compiled syndrome-extraction circuit in the wire format of the reference's CompiledCircuit (src/noise/compiled.py:116-173;
+ * op codes src/noise/constants.py:8-14).  All pointers are host pointers, copied at plan creation. */
+typedef struct {
+    int64_t base_len, suffix_len;                       /* noisy part (cycle * num_cycles) and noiseless suffix (cycle * 2) */
+    const int32_t *base_ops, *base_q1, *base_q2, *suffix_ops, *suffix_q1, *suffix_q2;
+    int32_t total_qubits, num_x_checks, num_z_checks, n_data, k, reserved;
+    const int32_t *x_syn_positions, *x_syn_ptrs;        /* CSR: X check -> indices of its MeasX outcomes (compiled.py:72-103) */
+    const int32_t *z_syn_positions, *z_syn_ptrs;
+    const int32_t *data_qubit_indices;                  /* [n_data] */
+    const uint8_t *Lx, *Lz;                             /* logical operators, dense k x n_data */
+} qldpc_circuit_desc;
+
+typedef struct qldpc_circuit_plan qldpc_circuit_plan;
+/* a13 + a14: run_trial_fast (src/noise/simulation.py:21-107) + _run_single_trial_fast and the tally
+ * (src/simulation/engine.py:68-122, 450-457), batched.  gz / gx: Tanner graphs of HdecZ / HdecX; prior_*: LLRs of
+ * engine.py:210-212; logmask_*[j]: bit r set iff logical row r of H*_full has a one in column j (engine.py:99,119).
+ * Trials are addressed by a global index (Philox streams), so any split over calls / devices gives the same tally. */
+int qldpc_circuit_plan_create(const qldpc_circuit_desc *circuit, const qldpc_graph *gz, const qldpc_graph *gx, const double *prior_z,
+                              const double *prior_x, const uint64_t *logmask_z, const uint64_t *logmask_x, double p, int max_iter,
+                              int alpha_mode, double alpha_val_z, double alpha_val_x, const double *alpha_seq_z, int alpha_len_z,
+                              const double *alpha_seq_x, int alpha_len_x, double damping, double clip_llr, int use_osd, int flags,
+                              int64_t batch, qldpc_circuit_plan **out);
+int qldpc_circuit_plan_run(qldpc_circuit_plan *plan, uint64_t seed, int64_t trial_begin, int64_t count, void *stream);
+int qldpc_circuit_plan_read(qldpc_circuit_plan *plan, void *stream, int clear, int64_t *tally);
+/* the sampler alone = batched run_trial_fast: sparse_z int8[count][#MeasX], true_z int8[count][k], sparse_x, true_x (host) */
+int qldpc_circuit_plan_sample(qldpc_circuit_plan *plan, uint64_t seed, int64_t trial_begin, int64_t count, int8_t *sparse_z,
+                              int8_t *true_z, int8_t *sparse_x, int8_t *true_x);
+void qldpc_circuit_plan_destroy(qldpc_circuit_plan *plan);
+
 /* Philox4x32-10 reference vector helper (host; lets tests pin the generator against the oracle) */
 void qldpc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -342,3 +342,76 @@ def cc_sample_decode_tally(indptr, indices, n, L, p, seed, shot_begin, count, ma
                                      _p(seq, C.c_double), C.c_int(seq.size), C.c_double(damping), C.c_double(clip_llr),
                                      C.c_int(int(use_osd)), C.c_int(threads), _p(tally, C.c_int64))
     return tally
+
+
+# ----------------------------------------------------------------------------- circuit-level trial (config 5)
+class _Circuit(C.Structure):
+    _fields_ = [("base_len", C.c_int64), ("suffix_len", C.c_int64),
+                ("base_ops", C.POINTER(C.c_int32)), ("base_q1", C.POINTER(C.c_int32)), ("base_q2", C.POINTER(C.c_int32)),
+                ("suffix_ops", C.POINTER(C.c_int32)), ("suffix_q1", C.POINTER(C.c_int32)), ("suffix_q2", C.POINTER(C.c_int32)),
+                ("total_qubits", C.c_int32), ("num_x_checks", C.c_int32), ("num_z_checks", C.c_int32), ("n_data", C.c_int32),
+                ("k", C.c_int32), ("pad_", C.c_int32),
+                ("x_syn_positions", C.POINTER(C.c_int32)), ("x_syn_ptrs", C.POINTER(C.c_int32)),
+                ("z_syn_positions", C.POINTER(C.c_int32)), ("z_syn_ptrs", C.POINTER(C.c_int32)),
+                ("data_qubit_indices", C.POINTER(C.c_int32)), ("Lx", C.POINTER(C.c_uint8)), ("Lz", C.POINTER(C.c_uint8))]
+
+
+class _Sector(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("indptr", C.POINTER(C.c_int32)), ("indices", C.POINTER(C.c_int32)),
+                ("prior", C.POINTER(C.c_double)), ("logmask", C.POINTER(C.c_uint64))]
+
+
+def _get(src, name):
+    return src[name] if isinstance(src, dict) else getattr(src, name)
+
+
+def make_circuit(src, Lx, Lz):
+    """src: dict or CompiledCircuit-like object with the compiled-circuit arrays.  Returns (struct, keepalive)."""
+    keep = {k: _i32(_get(src, k)) for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions",
+                                            "x_syn_ptrs", "z_syn_positions", "z_syn_ptrs", "data_qubit_indices")}
+    keep["Lx"], keep["Lz"] = _u8(Lx), _u8(Lz)
+    c = _Circuit()
+    c.base_len, c.suffix_len = keep["base_ops"].size, keep["suffix_ops"].size
+    for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions", "x_syn_ptrs", "z_syn_positions",
+              "z_syn_ptrs", "data_qubit_indices"):
+        setattr(c, k, _p(keep[k], C.c_int32))
+    c.total_qubits = int(_get(src, "total_qubits"))
+    c.num_x_checks, c.num_z_checks = keep["x_syn_ptrs"].size - 1, keep["z_syn_ptrs"].size - 1
+    c.n_data, c.k = keep["data_qubit_indices"].size, keep["Lx"].shape[0]
+    c.Lx, c.Lz = _p(keep["Lx"], C.c_uint8), _p(keep["Lz"], C.c_uint8)
+    return c, keep
+
+
+def make_sector(indptr, indices, n, prior, logical_indptr, logical_indices):
+    """Decoding sector: Hdec CSR + prior + logical rows (CSR, k x n) folded into one bit mask per column."""
+    ip, ix, pr = _i32(indptr), _i32(indices), _f64(prior)
+    lm = np.zeros(n, np.uint64)
+    lip, lix = np.asarray(logical_indptr), np.asarray(logical_indices)
+    for r in range(lip.size - 1):
+        lm[lix[lip[r]:lip[r + 1]]] |= np.uint64(1) << np.uint64(r)
+    s = _Sector()
+    s.m, s.n = ip.size - 1, int(n)
+    s.indptr, s.indices, s.prior, s.logmask = _p(ip, C.c_int32), _p(ix, C.c_int32), _p(pr, C.c_double), _p(lm, C.c_uint64)
+    return s, (ip, ix, pr, lm)
+
+
+def circuit_sample(circ, p, seed, trial):
+    c, _keep = circ
+    nsx = _keep["x_syn_ptrs"][-1]
+    nsz = _keep["z_syn_ptrs"][-1]
+    spz, spx = np.zeros(nsx, np.int8), np.zeros(nsz, np.int8)
+    tz, tx = np.zeros(c.k, np.int8), np.zeros(c.k, np.int8)
+    lib().orc_circuit_sample(C.byref(c), C.c_double(p), C.c_uint64(seed), C.c_uint64(trial), _p(spz, C.c_int8), _p(tz, C.c_int8),
+                             _p(spx, C.c_int8), _p(tx, C.c_int8))
+    return spz, tz, spx, tx
+
+
+def circuit_sample_decode_tally(circ, sec_z, sec_x, p, seed, trial_begin, count, max_iter=50, alpha=1.0, alpha_mode="dynamical",
+                                damping=1.0, clip_llr=20.0, use_osd=True, threads=0):
+    mode, aval, seq = _alpha_args(alpha_mode, alpha)
+    tally = np.zeros(16, np.int64)
+    lib().orc_circuit_sample_decode_tally(C.byref(circ[0]), C.byref(sec_z[0]), C.byref(sec_x[0]), C.c_double(p), C.c_uint64(seed),
+                                          C.c_int64(trial_begin), C.c_int64(count), C.c_int(max_iter), C.c_int(mode), C.c_double(aval),
+                                          _p(seq, C.c_double), C.c_int(seq.size), C.c_double(damping), C.c_double(clip_llr),
+                                          C.c_int(int(use_osd)), C.c_int(threads), _p(tally, C.c_int64))
+    return tally

@@ -611,3 +611,132 @@ ORC_API void orc_cc_sample_decode_tally(int m, int n, const int32_t *indptr, con
     tally[0] = count; tally[1] = t_err; tally[3] = t_err; tally[4] = t_conv; tally[6] = t_osd;
     tally[8] = t_it; tally[10] = t_zero; tally[12] = t_unsat;
 }
+
+/* ------------------------------------------------------------------------------------
+ * Circuit-level Monte-Carlo trial (BASELINE config 5): run_trial_fast (src/noise/simulation.py:21-107) driven by
+ * Philox instead of np.random, then _run_single_trial_fast (src/simulation/engine.py:68-122).
+ * Random draws of trial g (this project's definition; mc_common.h):
+ *   location l is faulty iff word (l & 3) of Philox(ctr = (g_lo, g_hi, l >> 2, 1)) < thr;
+ *   its Pauli choice is word 0 of Philox(ctr = (g_lo, g_hi, l, 2)) mod 3 (IDLE) / mod 15 (CNOT).
+ * The noisy circuit is then built and simulated literally with the a10-a12 functions above.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t base_len, suffix_len;
+    const int32_t *base_ops, *base_q1, *base_q2, *suffix_ops, *suffix_q1, *suffix_q2;
+    int32_t total_qubits, num_x_checks, num_z_checks, n_data, k, pad_;
+    const int32_t *x_syn_positions, *x_syn_ptrs, *z_syn_positions, *z_syn_ptrs, *data_qubit_indices;
+    const uint8_t *Lx, *Lz;
+} orc_circuit;
+
+static int64_t orc_count_locs(const orc_circuit *c) {
+    int64_t n = 0;
+    for (int64_t i = 0; i < c->base_len; i++) n += (c->base_ops[i] >= OP_CNOT && c->base_ops[i] <= OP_IDLE);
+    return n;
+}
+
+/* sparse_z[nsx], true_z[k], sparse_x[nsz], true_x[k] for global trial g */
+ORC_API void orc_circuit_sample(const orc_circuit *c, double p, uint64_t seed, uint64_t g,
+                                int8_t *sparse_z, int8_t *true_z, int8_t *sparse_x, int8_t *true_x) {
+    const int64_t n_locs = orc_count_locs(c);
+    const uint32_t thr = orc_bernoulli_threshold(p);
+    const int64_t cap = c->base_len + n_locs + c->suffix_len;
+    double *rv = (double *)malloc(sizeof(double) * (size_t)(n_locs + 1));
+    int32_t *rp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * n_locs + 2)), *rt = rp + n_locs + 1;
+    int32_t *oo = (int32_t *)malloc(sizeof(int32_t) * (size_t)(3 * cap + 3)), *o1 = oo + cap + 1, *o2 = o1 + cap + 1;
+    uint32_t o[4], w[4];
+    for (int64_t l = 0; l < n_locs; l++) {
+        if ((l & 3) == 0) philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(l >> 2), 1u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        const int fault = o[l & 3] < thr;
+        rv[l] = fault ? 0.0 : 1.0;                 /* rv < p  <=>  fault, for any p in (0,1) */
+        rp[l] = 0; rt[l] = 0;
+        if (fault) {
+            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)l, 2u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            rp[l] = (int32_t)(w[0] % 3u); rt[l] = (int32_t)(w[0] % 15u);
+        }
+    }
+    int64_t L = orc_generate_noisy_circuit(c->base_len, c->base_ops, c->base_q1, c->base_q2, p, rv, rp, rt, oo, o1, o2);
+    memcpy(oo + L, c->suffix_ops, sizeof(int32_t) * (size_t)c->suffix_len);           /* simulation.py:55-69 */
+    memcpy(o1 + L, c->suffix_q1, sizeof(int32_t) * (size_t)c->suffix_len);
+    memcpy(o2 + L, c->suffix_q2, sizeof(int32_t) * (size_t)c->suffix_len);
+    L += c->suffix_len;
+    const int nsx = c->x_syn_ptrs[c->num_x_checks], nsz = c->z_syn_ptrs[c->num_z_checks];
+    const int maxs = (nsx > nsz ? nsx : nsz) + 128;
+    int8_t *hist = (int8_t *)malloc((size_t)maxs), *state = (int8_t *)malloc((size_t)c->total_qubits + 1);
+    int8_t *data = (int8_t *)malloc((size_t)c->n_data + 1);
+    int64_t counts[2];
+    orc_simulate_circuit_z(L, oo, o1, o2, c->total_qubits, maxs, hist, state, counts);       /* simulation.py:72-88 */
+    orc_extract_data_state(state, c->data_qubit_indices, c->n_data, data);
+    orc_dense_matvec_mod2(c->k, c->n_data, c->Lx, data, true_z);
+    orc_sparsify_syndrome(hist, counts[0], c->x_syn_positions, c->x_syn_ptrs, c->num_x_checks, sparse_z);
+    orc_simulate_circuit_x(L, oo, o1, o2, c->total_qubits, maxs, hist, state, counts);       /* simulation.py:91-105 */
+    orc_extract_data_state(state, c->data_qubit_indices, c->n_data, data);
+    orc_dense_matvec_mod2(c->k, c->n_data, c->Lz, data, true_x);
+    orc_sparsify_syndrome(hist, counts[0], c->z_syn_positions, c->z_syn_ptrs, c->num_z_checks, sparse_x);
+    free(data); free(state); free(hist); free(oo); free(rp); free(rv);
+}
+
+typedef struct {            /* one decoding sector: Hdec (CSR), prior LLRs, logical rows of H_full as per-column bit masks */
+    int32_t m, n;
+    const int32_t *indptr, *indices;
+    const double *prior;
+    const uint64_t *logmask;
+} orc_sector;
+
+static int orc_decode_sector(const orc_sector *s, const int8_t *synd, const int8_t *true_log, int k, int max_iter, int alpha_mode,
+                             double alpha_val, const double *alpha_seq, int alpha_len, double damping, double clip, int use_osd,
+                             int8_t *cand, int8_t *sol, double *vals, double *work, int8_t *chk, int64_t *conv, int64_t *osd,
+                             int64_t *iters, int64_t *zero, int64_t *unsat) {
+    uint8_t cv;
+    const int fi = orc_minsum_decode(s->m, s->n, s->indptr, s->indices, synd, s->prior, max_iter, alpha_mode, alpha_val, alpha_seq,
+                                     alpha_len, damping, clip, cand, vals, &cv, work);                 /* engine.py:83-94 */
+    const int8_t *det = cand;
+    if (!cv && use_osd) { orc_osd0(s->m, s->n, s->indptr, s->indices, synd, vals, cand, NULL, sol); det = sol; (*osd)++; }   /* :96-97 */
+    uint64_t lm = 0;
+    for (int j = 0; j < s->n; j++) if (det[j] & 1) lm ^= s->logmask[j];                                  /* :99 dec = H_logical @ det */
+    uint64_t tl = 0;
+    for (int r = 0; r < k; r++) if (true_log[r] & 1) tl |= (uint64_t)1 << r;
+    orc_syndrome_check(s->m, s->indptr, s->indices, det, chk);
+    int nz = 0, bad = 0;
+    for (int i = 0; i < s->m; i++) { nz |= synd[i]; bad |= (chk[i] ^ synd[i]); }
+    *conv += cv; *iters += fi + 1; *zero += !nz; *unsat += (bad & 1);
+    return lm != tl;                                                                                      /* :100 */
+}
+
+ORC_API void orc_circuit_sample_decode_tally(const orc_circuit *c, const orc_sector *sz, const orc_sector *sx, double p, uint64_t seed,
+                                             int64_t trial_begin, int64_t count, int max_iter, int alpha_mode, double alpha_val,
+                                             const double *alpha_seq, int alpha_len, double damping, double clip, int use_osd,
+                                             int threads, int64_t *tally) {
+    int64_t T[16];
+    memset(T, 0, sizeof(T));
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        int64_t t[16];
+        memset(t, 0, sizeof(t));
+        const int nmax = sz->n > sx->n ? sz->n : sx->n, mmax = sz->m > sx->m ? sz->m : sx->m;
+        const int nnzmax = sz->indptr[sz->m] > sx->indptr[sx->m] ? sz->indptr[sz->m] : sx->indptr[sx->m];
+        double *work = (double *)malloc(sizeof(double) * (size_t)(3 * nnzmax + nmax + mmax + 1));
+        double *vals = (double *)malloc(sizeof(double) * (size_t)nmax);
+        int8_t *buf = (int8_t *)malloc((size_t)(2 * nmax + 3 * mmax + 2 * c->k + 8));
+        int8_t *cand = buf, *sol = cand + nmax, *spz = sol + nmax, *spx = spz + mmax, *chk = spx + mmax, *tz = chk + mmax, *tx = tz + c->k;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int64_t i = 0; i < count; i++) {
+            orc_circuit_sample(c, p, seed, (uint64_t)(trial_begin + i), spz, tz, spx, tx);
+            const int ze = orc_decode_sector(sz, spz, tz, c->k, max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, damping, clip, use_osd,
+                                             cand, sol, vals, work, chk, &t[4], &t[6], &t[8], &t[10], &t[12]);
+            const int xe = orc_decode_sector(sx, spx, tx, c->k, max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, damping, clip, use_osd,
+                                             cand, sol, vals, work, chk, &t[5], &t[7], &t[9], &t[11], &t[13]);
+            t[0]++; t[1] += ze; t[2] += xe; t[3] += (ze | xe);                                          /* engine.py:122, 450-457 */
+        }
+        free(buf); free(vals); free(work);
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        for (int q = 0; q < 16; q++) T[q] += t[q];
+    }
+    memcpy(tally, T, sizeof(T));
+}

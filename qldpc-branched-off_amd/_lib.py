@@ -22,7 +22,8 @@ EXPORTS = [
     "qldpc_bp_decode_batch", "qldpc_gf2_spmv_batch", "qldpc_gf2_eliminate", "qldpc_gf2_eliminate_packed", "qldpc_osd0_batch",
     "qldpc_noisy_circuit_batch", "qldpc_frame_sim_batch", "qldpc_sparsify_batch", "qldpc_cc_sample_decode_tally",
     "qldpc_cc_plan_create", "qldpc_cc_plan_run", "qldpc_cc_plan_read", "qldpc_cc_plan_kernel_time", "qldpc_cc_plan_destroy",
-    "qldpc_philox4x32_10",
+    "qldpc_philox4x32_10", "qldpc_circuit_plan_create", "qldpc_circuit_plan_run", "qldpc_circuit_plan_read", "qldpc_circuit_plan_sample",
+    "qldpc_circuit_plan_destroy",
 ]
 
 
@@ -46,11 +47,13 @@ def lib():
                 L = C.CDLL(SO_PATH)
                 L.qldpc_last_error.restype = C.c_char_p
                 for name in EXPORTS:
-                    if name not in ("qldpc_last_error", "qldpc_graph_destroy", "qldpc_cc_plan_destroy", "qldpc_philox4x32_10"):
+                    if name not in ("qldpc_last_error", "qldpc_graph_destroy", "qldpc_cc_plan_destroy", "qldpc_philox4x32_10",
+                                    "qldpc_circuit_plan_destroy"):
                         getattr(L, name).restype = C.c_int
                 L.qldpc_graph_destroy.restype = None
                 L.qldpc_cc_plan_destroy.restype = None
                 L.qldpc_philox4x32_10.restype = None
+                L.qldpc_circuit_plan_destroy.restype = None
                 _lib = L
     return _lib
 
@@ -235,6 +238,95 @@ class CodeCapacityPlan:
     def close(self):
         if self._h is not None and self._h.value:
             lib().qldpc_cc_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CircuitDesc(C.Structure):
+    """qldpc_circuit_desc (include/qldpc_hip.h)."""
+    _fields_ = [("base_len", C.c_int64), ("suffix_len", C.c_int64),
+                ("base_ops", C.POINTER(C.c_int32)), ("base_q1", C.POINTER(C.c_int32)), ("base_q2", C.POINTER(C.c_int32)),
+                ("suffix_ops", C.POINTER(C.c_int32)), ("suffix_q1", C.POINTER(C.c_int32)), ("suffix_q2", C.POINTER(C.c_int32)),
+                ("total_qubits", C.c_int32), ("num_x_checks", C.c_int32), ("num_z_checks", C.c_int32), ("n_data", C.c_int32),
+                ("k", C.c_int32), ("reserved", C.c_int32),
+                ("x_syn_positions", C.POINTER(C.c_int32)), ("x_syn_ptrs", C.POINTER(C.c_int32)),
+                ("z_syn_positions", C.POINTER(C.c_int32)), ("z_syn_ptrs", C.POINTER(C.c_int32)),
+                ("data_qubit_indices", C.POINTER(C.c_int32)), ("Lx", C.POINTER(C.c_uint8)), ("Lz", C.POINTER(C.c_uint8))]
+
+
+def _attr(src, name):
+    return src[name] if isinstance(src, dict) else getattr(src, name)
+
+
+def logical_column_masks(logical_rows, n):
+    """k x n logical rows of H*_full (dense 0/1 or (indptr, indices) CSR) -> uint64[n] with bit r = row r."""
+    lm = np.zeros(n, np.uint64)
+    if isinstance(logical_rows, tuple):
+        ip, ix = logical_rows
+        for r in range(len(ip) - 1):
+            lm[np.asarray(ix[ip[r]:ip[r + 1]], dtype=np.int64)] |= np.uint64(1) << np.uint64(r)
+    else:
+        M = np.asarray(logical_rows)
+        for r in range(M.shape[0]):
+            lm[np.flatnonzero(M[r])] |= np.uint64(1) << np.uint64(r)
+    return lm
+
+
+class CircuitPlan:
+    """Circuit-level Monte-Carlo plan (qldpc_circuit_plan_*): Philox fault sampling through precomputed fault signatures,
+    decode of both sectors, OSD-0, logical comparison and tally, all on the device."""
+
+    def __init__(self, compiled, Lx, Lz, graph_z, graph_x, prior_z, prior_x, logmask_z, logmask_x, p, max_iter=50, alpha_z=1.0, alpha_x=1.0,
+                 alpha_mode="dynamical", damping=1.0, clip_llr=20.0, use_osd=True, flags=0, batch=4096):
+        mode, az, sz = alpha_args(alpha_mode, alpha_z)
+        _, ax, sx = alpha_args(alpha_mode, alpha_x)
+        keep = {k: i32(_attr(compiled, k)) for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions",
+                                                     "x_syn_ptrs", "z_syn_positions", "z_syn_ptrs", "data_qubit_indices")}
+        keep["Lx"], keep["Lz"] = u8(Lx), u8(Lz)
+        d = CircuitDesc()
+        d.base_len, d.suffix_len = keep["base_ops"].size, keep["suffix_ops"].size
+        for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions", "x_syn_ptrs", "z_syn_positions",
+                  "z_syn_ptrs", "data_qubit_indices"):
+            setattr(d, k, ptr(keep[k], C.c_int32))
+        d.total_qubits = int(_attr(compiled, "total_qubits"))
+        d.num_x_checks, d.num_z_checks = keep["x_syn_ptrs"].size - 1, keep["z_syn_ptrs"].size - 1
+        d.n_data, d.k = keep["data_qubit_indices"].size, keep["Lx"].shape[0]
+        d.Lx, d.Lz = ptr(keep["Lx"], C.c_uint8), ptr(keep["Lz"], C.c_uint8)
+        pz, px = f64(prior_z), f64(prior_x)
+        lz, lx = np.ascontiguousarray(logmask_z, np.uint64), np.ascontiguousarray(logmask_x, np.uint64)
+        self.k, self.nsx, self.nsz = d.k, int(keep["x_syn_ptrs"][-1]), int(keep["z_syn_ptrs"][-1])
+        self.graph_z, self.graph_x = graph_z, graph_x
+        self._h = C.c_void_p()
+        check(lib().qldpc_circuit_plan_create(C.byref(d), graph_z.handle, graph_x.handle, ptr(pz, C.c_double), ptr(px, C.c_double),
+                                              ptr(lz, C.c_uint64), ptr(lx, C.c_uint64), C.c_double(p), C.c_int(max_iter), C.c_int(mode),
+                                              C.c_double(az), C.c_double(ax), ptr(sz, C.c_double), C.c_int(sz.size), ptr(sx, C.c_double),
+                                              C.c_int(sx.size), C.c_double(damping), C.c_double(clip_llr), C.c_int(int(use_osd)), C.c_int(flags),
+                                              C.c_int64(batch), C.byref(self._h)))
+
+    def run(self, seed, trial_begin, count, stream=0):
+        check(lib().qldpc_circuit_plan_run(self._h, C.c_uint64(seed), C.c_int64(trial_begin), C.c_int64(count), C.c_void_p(stream)))
+
+    def read(self, stream=0, clear=False):
+        tally = np.zeros(TALLY_SLOTS, np.int64)
+        check(lib().qldpc_circuit_plan_read(self._h, C.c_void_p(stream), C.c_int(int(clear)), ptr(tally, C.c_int64)))
+        return tally
+
+    def sample(self, seed, trial_begin, count):
+        """Batched run_trial_fast -> (sparse_z int8[count, nsx], true_z int8[count, k], sparse_x, true_x)."""
+        spz, spx = np.zeros((count, self.nsx), np.int8), np.zeros((count, self.nsz), np.int8)
+        tz, tx = np.zeros((count, self.k), np.int8), np.zeros((count, self.k), np.int8)
+        check(lib().qldpc_circuit_plan_sample(self._h, C.c_uint64(seed), C.c_int64(trial_begin), C.c_int64(count), ptr(spz, C.c_int8),
+                                              ptr(tz, C.c_int8), ptr(spx, C.c_int8), ptr(tx, C.c_int8)))
+        return spz, tz, spx, tx
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().qldpc_circuit_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

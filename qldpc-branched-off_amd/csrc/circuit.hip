@@ -1,0 +1,455 @@
+// Circuit-level Monte-Carlo (BASELINE config 5): run_trial_fast (reference src/noise/simulation.py:21-107) and the
+// per-trial pipeline _run_single_trial_fast (src/simulation/engine.py:68-122), batched on the device.
+//
+// MI355X-first formulation.  The reference builds a noisy op list per trial and walks ~20k ops twice.  Pauli-frame
+// propagation is linear over GF(2) in the inserted faults, so here the effect of ONE flip at every (error location,
+// qubit slot) -- its detector flips and logical flips, per sector -- is computed once per plan by a batched frame
+// simulation (one lane per single-fault circuit; the same thing the reference's builder.py:37-51 does to build H).
+// A trial is then: draw the faulty locations (Philox), XOR the signatures of their Pauli components into a bit-set in
+// LDS.  Equality with the literal simulation is asserted against the CPU checker on identical random draws.
+// Random draws of trial g: location l faulty iff word (l&3) of Philox(g, block l>>2, domain 1) < thr; its Pauli choice
+// is word 0 of Philox(g, l, domain 2) mod 3 (IDLE, noise/kernels.py:260-272) or mod 15 (CNOT, :274-344).
+#include "common.h"
+#include "mc_common.h"
+#include "minsum_common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace qldpc {
+
+enum { C_OP_CNOT = 1, C_OP_PREP_X = 2, C_OP_PREP_Z = 3, C_OP_MEAS_X = 4, C_OP_MEAS_Z = 5, C_OP_IDLE = 6 };   // noise/constants.py:8-14
+
+// ---- single-fault frame simulation: lane = (location, slot); ops shared; frames laid out [qubit][lane] ----
+template <bool XSECTOR>
+__global__ void fault_signature_kernel(int nl, const int32_t *__restrict__ lane_pos, const int8_t *__restrict__ lane_after,
+                                       const int32_t *__restrict__ lane_qubit, int64_t len, const int32_t *__restrict__ ops,
+                                       const int32_t *__restrict__ q1, const int32_t *__restrict__ q2, int tq, int nsyn,
+                                       int8_t *__restrict__ state, int8_t *__restrict__ hist) {
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= nl) return;
+    for (int q = 0; q < tq; q++) state[(size_t)q * nl + lane] = 0;
+    const int pos = lane_pos[lane], fq = lane_qubit[lane];
+    const bool after = lane_after[lane] != 0;
+    int sc = 0;
+    for (int64_t i = 0; i < len; i++) {
+        const int op = ops[i], a = q1[i], c = q2[i];
+        if (i == pos && !after && fq >= 0) state[(size_t)fq * nl + lane] ^= 1;       // Meas: flip BEFORE (kernels.py:210-221)
+        if (op == C_OP_CNOT) {
+            if (!XSECTOR) state[(size_t)a * nl + lane] ^= state[(size_t)c * nl + lane];   // Z: target -> control (kernels.py:55-57)
+            else state[(size_t)c * nl + lane] ^= state[(size_t)a * nl + lane];            // X: control -> target (kernels.py:136-138)
+        } else if (op == (XSECTOR ? C_OP_PREP_Z : C_OP_PREP_X)) {
+            state[(size_t)a * nl + lane] = 0;
+        } else if (op == (XSECTOR ? C_OP_MEAS_Z : C_OP_MEAS_X)) {
+            if (sc < nsyn) hist[(size_t)sc * nl + lane] = state[(size_t)a * nl + lane];
+            sc++;
+        }
+        if (i == pos && after && fq >= 0) state[(size_t)fq * nl + lane] ^= 1;        // Prep/CNOT: flip AFTER (kernels.py:236-258,274)
+    }
+}
+
+struct SigTab {           // signatures of one sector; entry e = 2 * location + slot
+    const int32_t *ptr;   // [2*n_locs + 1]
+    const uint16_t *idx;  // detector indices
+    const uint64_t *log;  // logical flips, bit r = logical row r
+};
+
+// component masks: bit0 = X on slot 0, bit1 = X on slot 1, bit2 = Z on slot 0, bit3 = Z on slot 1
+__constant__ uint8_t c_cnot_comp[15] = {1, 5, 4, 2, 10, 8, 3, 15, 12, 11, 7, 13, 14, 9, 6};   // order of noise/kernels.py:283-343
+__constant__ uint8_t c_idle_comp[3] = {1, 5, 4};                                               // X, Y, Z (kernels.py:263-268)
+
+__device__ __forceinline__ void xor_signature(const SigTab &T, int e, uint32_t *bits, unsigned long long *logacc) {
+    for (int k = T.ptr[e]; k < T.ptr[e + 1]; k++) { const int d = T.idx[k]; atomicXor(&bits[d >> 5], 1u << (d & 31)); }
+    const unsigned long long lm = T.log[e];
+    if (lm) atomicXor(logacc, lm);
+}
+
+// one workgroup per trial (grid-stride): draw faults, accumulate both sectors' detector bit-sets in LDS, write them out
+__global__ __launch_bounds__(256) void circuit_sample_kernel(int64_t B, int64_t trial_begin, uint32_t seed_lo, uint32_t seed_hi, uint32_t thr,
+                                                             int n_locs, const uint8_t *__restrict__ loc_type, SigTab Z, SigTab X, int nsx,
+                                                             int nsz, int8_t *__restrict__ syn_z, int8_t *__restrict__ syn_x,
+                                                             unsigned long long *__restrict__ true_z, unsigned long long *__restrict__ true_x) {
+    extern __shared__ uint32_t sm[];
+    const int wz = (nsx + 31) >> 5, wx = (nsz + 31) >> 5;
+    uint32_t *bz = sm, *bx = sm + wz;
+    unsigned long long *lacc = reinterpret_cast<unsigned long long *>(sm + ((wz + wx + 1) & ~1));
+    const int nblk = (n_locs + 3) >> 2;
+    for (int64_t t = blockIdx.x; t < B; t += gridDim.x) {
+        for (int w = threadIdx.x; w < wz + wx; w += blockDim.x) sm[w] = 0;
+        if (threadIdx.x < 2) lacc[threadIdx.x] = 0ull;
+        __syncthreads();
+        const uint64_t g = (uint64_t)(trial_begin + t);
+        for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
+            uint32_t o[4];
+            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)blk, 1u, seed_lo, seed_hi, o);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int l = 4 * blk + w;
+                if (l < n_locs && o[w] < thr) {
+                    const int ty = loc_type[l];
+                    int comp;
+                    if (ty == C_OP_MEAS_X || ty == C_OP_PREP_X) comp = 4;            // Z flip (kernels.py:211-216, 241-246)
+                    else if (ty == C_OP_MEAS_Z || ty == C_OP_PREP_Z) comp = 1;       // X flip (kernels.py:224-229, 253-258)
+                    else {
+                        uint32_t r[4];
+                        philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)l, 2u, seed_lo, seed_hi, r);
+                        comp = (ty == C_OP_IDLE) ? c_idle_comp[r[0] % 3u] : c_cnot_comp[r[0] % 15u];
+                    }
+                    if (comp & 1) xor_signature(X, 2 * l, bx, &lacc[1]);
+                    if (comp & 2) xor_signature(X, 2 * l + 1, bx, &lacc[1]);
+                    if (comp & 4) xor_signature(Z, 2 * l, bz, &lacc[0]);
+                    if (comp & 8) xor_signature(Z, 2 * l + 1, bz, &lacc[0]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nsx; i += blockDim.x) syn_z[t * nsx + i] = (bz[i >> 5] >> (i & 31)) & 1;
+        for (int i = threadIdx.x; i < nsz; i += blockDim.x) syn_x[t * nsz + i] = (bx[i >> 5] >> (i & 31)) & 1;
+        if (threadIdx.x == 0) { true_z[t] = lacc[0]; true_x[t] = lacc[1]; }
+        __syncthreads();
+    }
+}
+
+// per trial (32 lanes): decoded logical action H_logical @ det (engine.py:99,119) vs the true logical flips, both sectors
+struct JudgeSector {
+    int m, n;
+    const int32_t *indptr, *indices;
+    const uint64_t *logmask;
+    const int8_t *synd, *det;
+    const uint8_t *conv;
+    const int32_t *iters;
+    const unsigned long long *true_log;
+};
+
+__device__ __forceinline__ void judge_sector(const JudgeSector &S, int64_t b, int lane, bool &err, bool &nz, bool &bad) {
+    const int8_t *d = S.det + b * S.n, *s = S.synd + b * S.m;
+    uint64_t lm = 0;
+    for (int j = lane; j < S.n; j += 32) if (d[j] & 1) lm ^= S.logmask[j];
+    int bd = 0, z = 0;
+    for (int i = lane; i < S.m; i += 32) {
+        int p = 0;
+        for (int k = S.indptr[i]; k < S.indptr[i + 1]; k++) p ^= d[S.indices[k]];
+        bd |= ((p ^ s[i]) & 1);
+        z |= (s[i] & 1);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) { lm ^= __shfl_xor(lm, off, 32); bd |= __shfl_xor(bd, off, 32); z |= __shfl_xor(z, off, 32); }
+    err = (lm != S.true_log[b]);
+    nz = z != 0;
+    bad = bd != 0;
+}
+
+__global__ __launch_bounds__(256) void circuit_judge_kernel(int64_t B, JudgeSector Z, JudgeSector X, unsigned long long *__restrict__ tally) {
+    __shared__ unsigned long long acc[QLDPC_TALLY_SLOTS];
+    if (threadIdx.x < QLDPC_TALLY_SLOTS) acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 31;
+    const int64_t b = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (b < B) {
+        bool ze, zn, zb, xe, xn, xb;
+        judge_sector(Z, b, lane, ze, zn, zb);
+        judge_sector(X, b, lane, xe, xn, xb);
+        if (lane == 0) {
+            atomicAdd(&acc[QLDPC_TALLY_TRIALS], 1ull);
+            if (ze) atomicAdd(&acc[QLDPC_TALLY_Z_ERR], 1ull);
+            if (xe) atomicAdd(&acc[QLDPC_TALLY_X_ERR], 1ull);
+            if (ze || xe) atomicAdd(&acc[QLDPC_TALLY_TOTAL_ERR], 1ull);                       // engine.py:122
+            if (Z.conv[b]) atomicAdd(&acc[QLDPC_TALLY_BP_CONV_Z], 1ull);
+            if (X.conv[b]) atomicAdd(&acc[QLDPC_TALLY_BP_CONV_X], 1ull);
+            atomicAdd(&acc[QLDPC_TALLY_ITERS_Z], (unsigned long long)(Z.iters[b] + 1));
+            atomicAdd(&acc[QLDPC_TALLY_ITERS_X], (unsigned long long)(X.iters[b] + 1));
+            if (!zn) atomicAdd(&acc[QLDPC_TALLY_ZERO_SYND_Z], 1ull);
+            if (!xn) atomicAdd(&acc[QLDPC_TALLY_ZERO_SYND_X], 1ull);
+            if (zb) atomicAdd(&acc[QLDPC_TALLY_UNSAT_Z], 1ull);
+            if (xb) atomicAdd(&acc[QLDPC_TALLY_UNSAT_X], 1ull);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < QLDPC_TALLY_SLOTS && acc[threadIdx.x]) atomicAdd(&tally[threadIdx.x], acc[threadIdx.x]);
+}
+
+__global__ void collect_failed2_kernel(int64_t B, const uint8_t *__restrict__ conv, int32_t *__restrict__ list, int32_t *__restrict__ count) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && !conv[b]) list[atomicAdd(count, 1)] = (int32_t)b;
+}
+__global__ void add_count_kernel(const int32_t *count, unsigned long long *slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(slot, (unsigned long long)*count);
+}
+
+}  // namespace qldpc
+
+using namespace qldpc;
+
+struct qldpc_circuit_plan {
+    const qldpc_graph *gz = nullptr, *gx = nullptr;
+    int device = 0, k = 0, n_locs = 0, nsx = 0, nsz = 0, max_iter = 0, use_osd = 0, flags = 0;
+    double p = 0, damping = 1, clip = 20;
+    uint32_t thr = 0;
+    int64_t batch = 0;
+    bool nanfree = false;
+    DevBuf d_loc_type, d_zptr, d_zidx, d_zlog, d_xptr, d_xidx, d_xlog;
+    DevBuf d_alpha_z, d_alpha_x, d_prior_z, d_prior_x, d_lm_z, d_lm_x;
+    DevBuf d_syn_z, d_syn_x, d_true_z, d_true_x, d_det_z, d_det_x, d_llr_z, d_llr_x, d_conv_z, d_conv_x, d_iter_z, d_iter_x;
+    DevBuf d_list, d_count, d_tally;
+    std::vector<DevBuf *> all() {
+        return {&d_loc_type, &d_zptr, &d_zidx, &d_zlog, &d_xptr, &d_xidx, &d_xlog, &d_alpha_z, &d_alpha_x, &d_prior_z, &d_prior_x, &d_lm_z, &d_lm_x,
+                &d_syn_z, &d_syn_x, &d_true_z, &d_true_x, &d_det_z, &d_det_x, &d_llr_z, &d_llr_x, &d_conv_z, &d_conv_x, &d_iter_z, &d_iter_x,
+                &d_list, &d_count, &d_tally};
+    }
+};
+
+template <class T>
+static int up(DevBuf &b, const std::vector<T> &v) {
+    int rc = b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (rc != QLDPC_OK) return rc;
+    if (!v.empty()) QLDPC_HIP_TRY(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return QLDPC_OK;
+}
+
+// Builds the per-(location, slot) signatures of one sector with the batched single-fault frame simulation.
+static int build_signatures(const qldpc_circuit_desc *D, bool xsector, const std::vector<int32_t> &loc_op, const std::vector<int32_t> &ops,
+                            const std::vector<int32_t> &q1, const std::vector<int32_t> &q2, std::vector<int32_t> &ptr, std::vector<uint16_t> &idx,
+                            std::vector<uint64_t> &logm) {
+    const int n_locs = (int)loc_op.size(), nl = 2 * n_locs, tq = D->total_qubits;
+    const int32_t *spos = xsector ? D->z_syn_positions : D->x_syn_positions, *sptr = xsector ? D->z_syn_ptrs : D->x_syn_ptrs;
+    const int nchk = xsector ? D->num_z_checks : D->num_x_checks;
+    const int nsyn = sptr[nchk];
+    const uint8_t *L = xsector ? D->Lz : D->Lx;
+    std::vector<int32_t> lane_pos(nl), lane_q(nl);
+    std::vector<int8_t> lane_after(nl);
+    for (int l = 0; l < n_locs; l++) {
+        const int i = loc_op[l], op = D->base_ops[i];
+        for (int s = 0; s < 2; s++) {
+            const int e = 2 * l + s;
+            lane_pos[e] = i;
+            lane_after[e] = (op == C_OP_PREP_X || op == C_OP_PREP_Z || op == C_OP_CNOT) ? 1 : 0;      // Meas: before; Idle: either
+            lane_q[e] = (s == 0) ? D->base_q1[i] : (op == C_OP_CNOT ? D->base_q2[i] : -1);
+        }
+    }
+    DevTmp dpos, dafter, dq, dops, dq1, dq2, dstate, dhist;
+    int rc;
+    const size_t len = ops.size();
+    if ((rc = dpos.alloc(nl * 4)) || (rc = dafter.alloc(nl)) || (rc = dq.alloc(nl * 4)) || (rc = dops.alloc(len * 4)) || (rc = dq1.alloc(len * 4)) ||
+        (rc = dq2.alloc(len * 4)) || (rc = dstate.alloc((size_t)tq * nl)) || (rc = dhist.alloc((size_t)nsyn * nl)))
+        return rc;
+    QLDPC_HIP_TRY(hipMemcpy(dpos.p, lane_pos.data(), nl * 4, hipMemcpyHostToDevice));
+    QLDPC_HIP_TRY(hipMemcpy(dafter.p, lane_after.data(), nl, hipMemcpyHostToDevice));
+    QLDPC_HIP_TRY(hipMemcpy(dq.p, lane_q.data(), nl * 4, hipMemcpyHostToDevice));
+    QLDPC_HIP_TRY(hipMemcpy(dops.p, ops.data(), len * 4, hipMemcpyHostToDevice));
+    QLDPC_HIP_TRY(hipMemcpy(dq1.p, q1.data(), len * 4, hipMemcpyHostToDevice));
+    QLDPC_HIP_TRY(hipMemcpy(dq2.p, q2.data(), len * 4, hipMemcpyHostToDevice));
+    QLDPC_HIP_TRY(hipMemset(dhist.p, 0, (size_t)nsyn * nl));
+    const unsigned grid = (unsigned)((nl + 255) / 256);
+    if (xsector)
+        hipLaunchKernelGGL(fault_signature_kernel<true>, dim3(grid), dim3(256), 0, nullptr, nl, dpos.as<int32_t>(), dafter.as<int8_t>(), dq.as<int32_t>(),
+                           (int64_t)len, dops.as<int32_t>(), dq1.as<int32_t>(), dq2.as<int32_t>(), tq, nsyn, dstate.as<int8_t>(), dhist.as<int8_t>());
+    else
+        hipLaunchKernelGGL(fault_signature_kernel<false>, dim3(grid), dim3(256), 0, nullptr, nl, dpos.as<int32_t>(), dafter.as<int8_t>(), dq.as<int32_t>(),
+                           (int64_t)len, dops.as<int32_t>(), dq1.as<int32_t>(), dq2.as<int32_t>(), tq, nsyn, dstate.as<int8_t>(), dhist.as<int8_t>());
+    QLDPC_HIP_TRY(hipGetLastError());
+    QLDPC_HIP_TRY(hipDeviceSynchronize());
+    std::vector<int8_t> hist((size_t)nsyn * nl), state((size_t)tq * nl);
+    QLDPC_HIP_TRY(hipMemcpy(hist.data(), dhist.p, hist.size(), hipMemcpyDeviceToHost));
+    QLDPC_HIP_TRY(hipMemcpy(state.data(), dstate.p, state.size(), hipMemcpyDeviceToHost));
+    // detectors = XOR of consecutive RAW measurements of the same check (sparsify_syndrome_jit, kernels.py:356-380)
+    ptr.assign(nl + 1, 0); idx.clear(); logm.assign(nl, 0);
+    std::vector<int32_t> prev(nsyn, -1);
+    for (int c = 0; c < nchk; c++)
+        for (int i = sptr[c] + 1; i < sptr[c + 1]; i++) prev[spos[i]] = spos[i - 1];
+    for (int e = 0; e < nl; e++) {
+        if (lane_q[e] >= 0)
+            for (int s = 0; s < nsyn; s++) {
+                int v = hist[(size_t)s * nl + e];
+                if (prev[s] >= 0) v ^= hist[(size_t)prev[s] * nl + e];
+                if (v & 1) idx.push_back((uint16_t)s);
+            }
+        ptr[e + 1] = (int32_t)idx.size();
+        uint64_t lm = 0;
+        if (lane_q[e] >= 0)
+            for (int r = 0; r < D->k; r++) {                          // true logical = L @ data_state (simulation.py:80-81, 98-99)
+                int s = 0;
+                for (int j = 0; j < D->n_data; j++) s ^= (L[(size_t)r * D->n_data + j] & state[(size_t)D->data_qubit_indices[j] * nl + e] & 1);
+                if (s) lm |= (uint64_t)1 << r;
+            }
+        logm[e] = lm;
+    }
+    return QLDPC_OK;
+}
+
+static int validate_desc(const qldpc_circuit_desc *D) {
+    QLDPC_REQUIRE(D != nullptr, "circuit descriptor is NULL");
+    QLDPC_REQUIRE(D->base_len >= 0 && D->suffix_len >= 0 && D->total_qubits > 0, "bad circuit sizes");
+    QLDPC_REQUIRE(D->base_ops && D->base_q1 && D->base_q2 && (D->suffix_len == 0 || (D->suffix_ops && D->suffix_q1 && D->suffix_q2)), "NULL op array");
+    QLDPC_REQUIRE(D->x_syn_positions && D->x_syn_ptrs && D->z_syn_positions && D->z_syn_ptrs && D->data_qubit_indices && D->Lx && D->Lz, "NULL table");
+    QLDPC_REQUIRE(D->k >= 0 && D->k <= 64, "k out of range (0..64)");
+    for (int pass = 0; pass < 2; pass++) {
+        const int64_t len = pass ? D->suffix_len : D->base_len;
+        const int32_t *o = pass ? D->suffix_ops : D->base_ops, *a = pass ? D->suffix_q1 : D->base_q1, *c = pass ? D->suffix_q2 : D->base_q2;
+        for (int64_t i = 0; i < len; i++) {
+            QLDPC_REQUIRE(o[i] >= C_OP_CNOT && o[i] <= C_OP_IDLE, "op %d at %lld is not a base-circuit gate", o[i], (long long)i);
+            QLDPC_REQUIRE(a[i] >= 0 && a[i] < D->total_qubits, "q1 out of range at op %lld", (long long)i);
+            QLDPC_REQUIRE(o[i] != C_OP_CNOT || (c[i] >= 0 && c[i] < D->total_qubits), "q2 out of range at op %lld", (long long)i);
+        }
+    }
+    for (int j = 0; j < D->n_data; j++) QLDPC_REQUIRE(D->data_qubit_indices[j] >= 0 && D->data_qubit_indices[j] < D->total_qubits, "data qubit index out of range");
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_circuit_plan_create(const qldpc_circuit_desc *D, const qldpc_graph *gz, const qldpc_graph *gx, const double *prior_z,
+                                           const double *prior_x, const uint64_t *logmask_z, const uint64_t *logmask_x, double p, int max_iter,
+                                           int alpha_mode, double alpha_val_z, double alpha_val_x, const double *alpha_seq_z, int alpha_len_z,
+                                           const double *alpha_seq_x, int alpha_len_x, double damping, double clip_llr, int use_osd, int flags,
+                                           int64_t batch, qldpc_circuit_plan **out) {
+    QLDPC_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int rc = validate_desc(D);
+    if (rc != QLDPC_OK) return rc;
+    QLDPC_REQUIRE(gz && gx && prior_z && prior_x && logmask_z && logmask_x, "NULL argument");
+    QLDPC_REQUIRE(p > 0.0 && p < 1.0, "error rate must be in (0,1)");
+    QLDPC_REQUIRE(batch > 0 && batch <= (1 << 24), "batch out of range");
+    QLDPC_REQUIRE(gz->device == gx->device, "both sector graphs must live on the same device");
+    const int nsx = D->x_syn_ptrs[D->num_x_checks], nsz = D->z_syn_ptrs[D->num_z_checks];
+    QLDPC_REQUIRE(gz->m == nsx && gx->m == nsz, "decoding matrices have %d / %d rows but the circuit measures %d X / %d Z syndromes", gz->m, gx->m, nsx, nsz);
+    QLDPC_REQUIRE(nsx < 65536 && nsz < 65536, "too many detectors for 16-bit signature indices");
+    if ((rc = use_device(gz->device)) != QLDPC_OK) return rc;
+
+    std::vector<int32_t> ops(D->base_ops, D->base_ops + D->base_len), q1(D->base_q1, D->base_q1 + D->base_len), q2(D->base_q2, D->base_q2 + D->base_len);
+    ops.insert(ops.end(), D->suffix_ops, D->suffix_ops + D->suffix_len);
+    q1.insert(q1.end(), D->suffix_q1, D->suffix_q1 + D->suffix_len);
+    q2.insert(q2.end(), D->suffix_q2, D->suffix_q2 + D->suffix_len);
+    std::vector<int32_t> loc_op;               // every base op is an error location (kernels.py:206-351 visits them in order)
+    std::vector<uint8_t> loc_type;
+    for (int64_t i = 0; i < D->base_len; i++) { loc_op.push_back((int32_t)i); loc_type.push_back((uint8_t)D->base_ops[i]); }
+
+    qldpc_circuit_plan *P = new qldpc_circuit_plan();
+    auto fail = [&](int code) { qldpc_circuit_plan_destroy(P); return code; };
+    P->gz = gz; P->gx = gx; P->device = gz->device; P->k = D->k; P->n_locs = (int)loc_op.size(); P->nsx = nsx; P->nsz = nsz;
+    P->max_iter = max_iter; P->use_osd = use_osd; P->flags = flags; P->p = p; P->damping = damping; P->clip = clip_llr; P->batch = batch;
+    P->thr = bernoulli_threshold(p);
+    std::vector<double> az, ax;
+    if ((rc = build_alpha_table(max_iter, alpha_mode, alpha_val_z, alpha_seq_z, alpha_len_z, az)) != QLDPC_OK) return fail(rc);
+    if ((rc = build_alpha_table(max_iter, alpha_mode, alpha_val_x, alpha_seq_x, alpha_len_x, ax)) != QLDPC_OK) return fail(rc);
+    P->nanfree = false;      // circuit-level graphs have degree-1 checks (+-inf messages): keep the NaN test (SURVEY hard parts)
+    std::vector<int32_t> zp, xp;
+    std::vector<uint16_t> zi, xi;
+    std::vector<uint64_t> zl, xl;
+    if ((rc = build_signatures(D, false, loc_op, ops, q1, q2, zp, zi, zl)) != QLDPC_OK) return fail(rc);
+    if ((rc = build_signatures(D, true, loc_op, ops, q1, q2, xp, xi, xl)) != QLDPC_OK) return fail(rc);
+    if ((rc = up(P->d_loc_type, loc_type)) || (rc = up(P->d_zptr, zp)) || (rc = up(P->d_zidx, zi)) || (rc = up(P->d_zlog, zl)) || (rc = up(P->d_xptr, xp)) ||
+        (rc = up(P->d_xidx, xi)) || (rc = up(P->d_xlog, xl)) || (rc = up(P->d_alpha_z, az)) || (rc = up(P->d_alpha_x, ax)))
+        return fail(rc);
+    std::vector<double> pz(prior_z, prior_z + gz->n), px(prior_x, prior_x + gx->n);
+    std::vector<uint64_t> lz(logmask_z, logmask_z + gz->n), lx(logmask_x, logmask_x + gx->n);
+    if ((rc = up(P->d_prior_z, pz)) || (rc = up(P->d_prior_x, px)) || (rc = up(P->d_lm_z, lz)) || (rc = up(P->d_lm_x, lx))) return fail(rc);
+    const size_t Bz = (size_t)batch;
+    if ((rc = P->d_syn_z.ensure(Bz * nsx)) || (rc = P->d_syn_x.ensure(Bz * nsz)) || (rc = P->d_true_z.ensure(Bz * 8)) || (rc = P->d_true_x.ensure(Bz * 8)) ||
+        (rc = P->d_det_z.ensure(Bz * gz->n)) || (rc = P->d_det_x.ensure(Bz * gx->n)) || (rc = P->d_llr_z.ensure(Bz * gz->n * 8)) ||
+        (rc = P->d_llr_x.ensure(Bz * gx->n * 8)) || (rc = P->d_conv_z.ensure(Bz)) || (rc = P->d_conv_x.ensure(Bz)) || (rc = P->d_iter_z.ensure(Bz * 4)) ||
+        (rc = P->d_iter_x.ensure(Bz * 4)) || (rc = P->d_list.ensure(Bz * 4)) || (rc = P->d_count.ensure(16)) || (rc = P->d_tally.ensure(QLDPC_TALLY_SLOTS * 8)))
+        return fail(rc);
+    if (hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
+    *out = P;
+    return QLDPC_OK;
+}
+
+static int launch_sampler(qldpc_circuit_plan *P, uint64_t seed, int64_t begin, int64_t B, hipStream_t s) {
+    SigTab Z{P->d_zptr.as<int32_t>(), P->d_zidx.as<uint16_t>(), P->d_zlog.as<uint64_t>()};
+    SigTab X{P->d_xptr.as<int32_t>(), P->d_xidx.as<uint16_t>(), P->d_xlog.as<uint64_t>()};
+    const int wz = (P->nsx + 31) / 32, wx = (P->nsz + 31) / 32;
+    const size_t lds = (size_t)((wz + wx + 1) & ~1) * 4 + 16;
+    const unsigned grid = (unsigned)std::min<int64_t>(B, 256 * 16);
+    hipLaunchKernelGGL(circuit_sample_kernel, dim3(grid), dim3(256), lds, s, B, begin, (uint32_t)seed, (uint32_t)(seed >> 32), P->thr, P->n_locs,
+                       P->d_loc_type.as<uint8_t>(), Z, X, P->nsx, P->nsz, P->d_syn_z.as<int8_t>(), P->d_syn_x.as<int8_t>(),
+                       P->d_true_z.as<unsigned long long>(), P->d_true_x.as<unsigned long long>());
+    QLDPC_HIP_TRY(hipGetLastError());
+    return QLDPC_OK;
+}
+
+static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B, DevBuf &syn, DevBuf &prior, DevBuf &alpha, DevBuf &det, DevBuf &llr,
+                         DevBuf &conv, DevBuf &iter, int osd_slot, hipStream_t s) {
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        rc = minsum_decode_dispatch(g, B, syn.as<int8_t>(), prior.as<double>(), P->max_iter, alpha.as<double>(), P->damping, P->clip, P->flags,
+                                    P->nanfree, det.as<int8_t>(), llr.as<double>(), conv.as<uint8_t>(), iter.as<int32_t>(), s);
+    }
+    if (rc != QLDPC_OK || !P->use_osd) return rc;
+    QLDPC_HIP_TRY(hipMemsetAsync(P->d_count.p, 0, 4, s));
+    hipLaunchKernelGGL(collect_failed2_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, conv.as<uint8_t>(), P->d_list.as<int32_t>(),
+                       P->d_count.as<int32_t>());
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), syn.as<int8_t>(), llr.as<double>(), det.as<int8_t>(), nullptr,
+                                det.as<int8_t>(), s);
+    }
+    if (rc != QLDPC_OK) return rc;
+    hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(64), 0, s, P->d_count.as<int32_t>(), P->d_tally.as<unsigned long long>() + osd_slot);
+    QLDPC_HIP_TRY(hipGetLastError());
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_circuit_plan_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin, int64_t count, void *stream) {
+    QLDPC_REQUIRE(P != nullptr, "plan is NULL");
+    QLDPC_REQUIRE(count >= 0 && trial_begin >= 0, "negative trial range");
+    int rc = use_device(P->device);
+    if (rc != QLDPC_OK) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int64_t off = 0; off < count; off += P->batch) {
+        const int64_t B = std::min<int64_t>(P->batch, count - off);
+        if ((rc = launch_sampler(P, seed, trial_begin + off, B, s)) != QLDPC_OK) return rc;
+        if ((rc = decode_sector(P, P->gz, B, P->d_syn_z, P->d_prior_z, P->d_alpha_z, P->d_det_z, P->d_llr_z, P->d_conv_z, P->d_iter_z, QLDPC_TALLY_OSD_Z, s)) != QLDPC_OK) return rc;
+        if ((rc = decode_sector(P, P->gx, B, P->d_syn_x, P->d_prior_x, P->d_alpha_x, P->d_det_x, P->d_llr_x, P->d_conv_x, P->d_iter_x, QLDPC_TALLY_OSD_X, s)) != QLDPC_OK) return rc;
+        JudgeSector Z{P->gz->m, P->gz->n, P->gz->d_indptr, P->gz->d_indices, P->d_lm_z.as<uint64_t>(), P->d_syn_z.as<int8_t>(), P->d_det_z.as<int8_t>(),
+                      P->d_conv_z.as<uint8_t>(), P->d_iter_z.as<int32_t>(), P->d_true_z.as<unsigned long long>()};
+        JudgeSector X{P->gx->m, P->gx->n, P->gx->d_indptr, P->gx->d_indices, P->d_lm_x.as<uint64_t>(), P->d_syn_x.as<int8_t>(), P->d_det_x.as<int8_t>(),
+                      P->d_conv_x.as<uint8_t>(), P->d_iter_x.as<int32_t>(), P->d_true_x.as<unsigned long long>()};
+        hipLaunchKernelGGL(circuit_judge_kernel, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, B, Z, X, P->d_tally.as<unsigned long long>());
+        QLDPC_HIP_TRY(hipGetLastError());
+    }
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_circuit_plan_read(qldpc_circuit_plan *P, void *stream, int clear, int64_t *tally) {
+    QLDPC_REQUIRE(P != nullptr && tally != nullptr, "NULL argument");
+    int rc = use_device(P->device);
+    if (rc != QLDPC_OK) return rc;
+    QLDPC_HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    QLDPC_HIP_TRY(hipMemcpy(tally, P->d_tally.p, QLDPC_TALLY_SLOTS * 8, hipMemcpyDeviceToHost));
+    if (clear) QLDPC_HIP_TRY(hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8));
+    return QLDPC_OK;
+}
+
+// batched run_trial_fast: sparse_z int8[count][nsx], true_z int8[count][k], sparse_x int8[count][nsz], true_x int8[count][k] (host)
+QLDPC_EXPORT int qldpc_circuit_plan_sample(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin, int64_t count, int8_t *sparse_z,
+                                           int8_t *true_z, int8_t *sparse_x, int8_t *true_x) {
+    QLDPC_REQUIRE(P != nullptr, "plan is NULL");
+    QLDPC_REQUIRE(count >= 0 && trial_begin >= 0, "negative trial range");
+    QLDPC_REQUIRE(count == 0 || (sparse_z && true_z && sparse_x && true_x), "NULL output");
+    int rc = use_device(P->device);
+    if (rc != QLDPC_OK) return rc;
+    std::vector<unsigned long long> tz, tx;
+    for (int64_t off = 0; off < count; off += P->batch) {
+        const int64_t B = std::min<int64_t>(P->batch, count - off);
+        if ((rc = launch_sampler(P, seed, trial_begin + off, B, nullptr)) != QLDPC_OK) return rc;
+        QLDPC_HIP_TRY(hipDeviceSynchronize());
+        QLDPC_HIP_TRY(hipMemcpy(sparse_z + off * P->nsx, P->d_syn_z.p, (size_t)B * P->nsx, hipMemcpyDeviceToHost));
+        QLDPC_HIP_TRY(hipMemcpy(sparse_x + off * P->nsz, P->d_syn_x.p, (size_t)B * P->nsz, hipMemcpyDeviceToHost));
+        tz.resize(B); tx.resize(B);
+        QLDPC_HIP_TRY(hipMemcpy(tz.data(), P->d_true_z.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+        QLDPC_HIP_TRY(hipMemcpy(tx.data(), P->d_true_x.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+        for (int64_t b = 0; b < B; b++)
+            for (int r = 0; r < P->k; r++) {
+                true_z[(off + b) * P->k + r] = (int8_t)((tz[b] >> r) & 1);
+                true_x[(off + b) * P->k + r] = (int8_t)((tx[b] >> r) & 1);
+            }
+    }
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT void qldpc_circuit_plan_destroy(qldpc_circuit_plan *P) {
+    if (!P) return;
+    (void)hipSetDevice(P->device);
+    for (DevBuf *b : P->all()) b->release();
+    delete P;
+}

@@ -258,3 +258,47 @@ def test_philox_known_answer(L, oracle):
         c = np.array(ctr, np.uint32); k = np.array(key, np.uint32); o = np.zeros(4, np.uint32)
         L.lib().qldpc_philox4x32_10(L.ptr(c, C.c_uint32), L.ptr(k, C.c_uint32), L.ptr(o, C.c_uint32))
         assert np.array_equal(o, oracle.philox(c, k))
+
+
+def _circuit_setup(L, oracle, tag, golden):
+    from qldpc_amd.data import load_circuit_matrices
+    g = golden(tag + "_noise")
+    d = load_circuit_matrices(tag)
+    circ = oracle.make_circuit(g, g["Lx"], g["Lz"])
+    secs, graphs, priors, masks = [], [], [], []
+    for s in "ZX":
+        n = int(d[f"Hdec{s}_shape"][1])
+        prior = oracle.prior_llrs(d[f"channel_probs{s}"])
+        secs.append(oracle.make_sector(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], n, prior, d[f"H{s}_logical_indptr"], d[f"H{s}_logical_indices"]))
+        graphs.append(L.Graph(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], n))
+        priors.append(prior)
+        masks.append(L.logical_column_masks((d[f"H{s}_logical_indptr"], d[f"H{s}_logical_indices"]), n))
+    return g, circ, secs, graphs, priors, masks
+
+
+@pytest.mark.parametrize("tag,ntrial", [("circ72", 96), ("circ144", 24)])
+def test_circuit_sampler_equals_literal_simulation(L, oracle, golden, tag, ntrial):
+    """Signature-XOR sampler on the GPU == the oracle's literal noisy-circuit simulation on the same Philox draws (a10-a13)."""
+    g, circ, secs, graphs, priors, masks = _circuit_setup(L, oracle, tag, golden)
+    for p in (0.005, 0.05):
+        plan = L.CircuitPlan(g, g["Lx"], g["Lz"], graphs[0], graphs[1], priors[0], priors[1], masks[0], masks[1], p, batch=64)
+        spz, tz, spx, tx = plan.sample(4242, 1000, ntrial)          # more trials than one batch -> exercises chunking
+        for t in range(ntrial):
+            a, b, c, d = oracle.circuit_sample(circ, p, 4242, 1000 + t)
+            assert np.array_equal(spz[t], a) and np.array_equal(tz[t], b) and np.array_equal(spx[t], c) and np.array_equal(tx[t], d), (tag, p, t)
+        assert spz.any() and spx.any() and tz.any()
+        plan.close()
+
+
+@pytest.mark.parametrize("tag,ntrial", [("circ72", 200), ("circ144", 40)])
+def test_circuit_level_tally_matches_oracle(L, oracle, golden, tag, ntrial):
+    g, circ, secs, graphs, priors, masks = _circuit_setup(L, oracle, tag, golden)
+    p = 0.005
+    ref = oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], p, 77, 0, ntrial, max_iter=50, threads=0)
+    plan = L.CircuitPlan(g, g["Lx"], g["Lz"], graphs[0], graphs[1], priors[0], priors[1], masks[0], masks[1], p, max_iter=50, batch=64)
+    plan.run(77, 0, ntrial // 2)
+    plan.run(77, ntrial // 2, ntrial - ntrial // 2)              # split invariance
+    t = plan.read()
+    assert np.array_equal(t, ref), (t.tolist(), ref.tolist())
+    assert ref[L.TALLY["osd_z"]] > 0 and ref[L.TALLY["unsat_z"]] == 0 and ref[L.TALLY["total_err"]] > 0
+    plan.close()
