@@ -41,3 +41,16 @@ def load_circuit_matrices(tag):
     """Circuit-level decoding matrices (tag 'circ72' or 'circ144', p = 0.005) in CSR form."""
     with np.load(os.path.join(_HERE, f"{tag}_p005.npz")) as d:
         return {k: d[k] for k in d.files}
+
+
+def load_precomputed_matrices(tag):
+    """The same data as a dict run_simulation accepts as ``precomputed_matrices`` (sparse Hdec, logical rows as CSR tuples)."""
+    import scipy.sparse as sp
+    d = load_circuit_matrices(tag)
+    out = {"channel_probsZ": d["channel_probsZ"], "channel_probsX": d["channel_probsX"], "num_cycles": int(d["num_cycles"]), "k": int(d["k"])}
+    for s in ("Z", "X"):
+        m, n = (int(x) for x in d[f"Hdec{s}_shape"])
+        ix, ip = d[f"Hdec{s}_indices"], d[f"Hdec{s}_indptr"]
+        out[f"Hdec{s}"] = sp.csr_matrix((np.ones(ix.size, np.int8), ix, ip), shape=(m, n))
+        out[f"H{s}_logical"] = (d[f"H{s}_logical_indptr"], d[f"H{s}_logical_indices"])
+    return out

@@ -302,3 +302,20 @@ def test_circuit_level_tally_matches_oracle(L, oracle, golden, tag, ntrial):
     assert np.array_equal(t, ref), (t.tolist(), ref.tolist())
     assert ref[L.TALLY["osd_z"]] > 0 and ref[L.TALLY["unsat_z"]] == 0 and ref[L.TALLY["total_err"]] > 0
     plan.close()
+
+
+def test_run_simulation_mirror(L, oracle, golden):
+    """run_simulation (engine.py:193-488) on [[72,12,6]] x 6 cycles against the oracle tally for the same trial stream."""
+    from qldpc_amd.data import load_code, load_precomputed_matrices
+    from qldpc_amd.simulation.engine import run_simulation
+    c = load_code("bb72")
+    g, circ, secs, graphs, priors, masks = _circuit_setup(L, oracle, "circ72", golden)
+    bb = dict(ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+    res = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=150, num_cycles=6, maxIter=50, osd_order=0,
+                         precomputed_matrices=load_precomputed_matrices("circ72"), base_seed=31337, batch=64, **bb)
+    ref = oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], 0.005, 31337, 0, 150, max_iter=50, threads=0)
+    assert np.array_equal(res["tally"], ref)
+    assert res["num_trials"] == 150 and res["logical_errors"] == ref[3] and abs(res["logical_error_rate"] - ref[3] / 150) < 1e-12
+    assert set(["logical_error_rate", "z_logical_error_rate", "x_logical_error_rate", "num_trials", "logical_errors"]) <= set(res)
+    with pytest.raises(NotImplementedError):
+        run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=10, num_cycles=6, **bb)

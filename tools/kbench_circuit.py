@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Circuit-level (config 5) throughput probe on one GPU: python tools/kbench_circuit.py [--tag circ144] [--trials N] [--batch B]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import qldpc_amd  # noqa: F401,E402
+from qldpc_amd import _lib  # noqa: E402
+from qldpc_amd.data import load_code, load_circuit_matrices  # noqa: E402
+from qldpc_amd.codes.bb_code import BBCodeCircuit  # noqa: E402
+from qldpc_amd.noise.compiled import CompiledCircuit  # noqa: E402
+from qldpc_amd.simulation.engine import prior_llrs  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--tag", default="circ144")
+ap.add_argument("--trials", type=int, default=4096)
+ap.add_argument("--batch", type=int, default=2048)
+ap.add_argument("--max-iter", type=int, default=50)
+ap.add_argument("--no-osd", action="store_true")
+ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
+a = ap.parse_args()
+d = load_circuit_matrices(a.tag)
+c = load_code(str(d["code"]))
+cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=int(d["num_cycles"]), ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"],
+                   a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+comp = CompiledCircuit(cb.get_full_circuit(), cb.cycle * 2, cb.lin_order, cb.data_qubits, cb.Xchecks, cb.Zchecks)
+gr, pr, mk = [], [], []
+for s in "ZX":
+    n = int(d[f"Hdec{s}_shape"][1])
+    gr.append(_lib.Graph(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], n))
+    pr.append(prior_llrs(d[f"channel_probs{s}"]))
+    mk.append(_lib.logical_column_masks((d[f"H{s}_logical_indptr"], d[f"H{s}_logical_indices"]), n))
+t0 = time.perf_counter()
+plan = _lib.CircuitPlan(comp, c["Lx"], c["Lz"], gr[0], gr[1], pr[0], pr[1], mk[0], mk[1], 0.005, max_iter=a.max_iter, use_osd=not a.no_osd,
+                        flags=a.flags, batch=a.batch)
+print(f"plan create (signature tables): {time.perf_counter() - t0:.2f}s", flush=True)
+plan.run(1, 0, min(a.batch, 256)); plan.read(clear=True)
+t0 = time.perf_counter()
+spz, tz, spx, tx = plan.sample(5, 0, min(a.trials, 4096))
+dt = time.perf_counter() - t0
+print(f"sampler alone (incl. D2H): {min(a.trials, 4096) / dt:.0f} trials/s; mean syndrome weight Z {spz.sum(1).mean():.1f} X {spx.sum(1).mean():.1f}", flush=True)
+t0 = time.perf_counter()
+plan.run(5, 0, a.trials)
+t = plan.read()
+dt = time.perf_counter() - t0
+T = _lib.TALLY
+print(f"{a.tag} max_iter={a.max_iter} osd={not a.no_osd}: {a.trials / dt:.1f} trials/s ({dt:.2f}s); LER={t[T['total_err']] / t[0]:.3f} "
+      f"conv_z={t[T['bp_conv_z']] / t[0]:.2f} conv_x={t[T['bp_conv_x']] / t[0]:.2f} osd={t[T['osd_z']]}+{t[T['osd_x']]} "
+      f"mean_it_z={t[T['iters_z']] / t[0]:.1f} unsat={t[T['unsat_z']]}+{t[T['unsat_x']]}", flush=True)
