@@ -122,6 +122,19 @@ QLDPC_EXPORT int qldpc_graph_create(int m, int n, const int32_t *indptr, const i
     if (rc == QLDPC_OK) rc = upload(&g->d_rowidx, g->rowidx);
     if (rc == QLDPC_OK) rc = upload(&g->d_csc2csr, g->csc2csr);
     if (rc == QLDPC_OK) rc = upload(&g->d_csr2csc, g->csr2csc);
+    if (rc == QLDPC_OK && n < 65535 && m < (1 << 24) && g->max_row_deg < 256) {
+        std::vector<uint16_t> ec((size_t)std::max(g->max_row_deg, 1) * std::max(m, 1), 0xFFFF);
+        std::vector<uint32_t> ev((size_t)std::max(g->max_col_deg, 1) * std::max(n, 1), 0xFFFFFFFFu);
+        for (int i = 0; i < m; i++)
+            for (int e = indptr[i]; e < indptr[i + 1]; e++) ec[(size_t)(e - indptr[i]) * m + i] = (uint16_t)indices[e];
+        for (int j = 0; j < n; j++)
+            for (int k = g->colptr[j]; k < g->colptr[j + 1]; k++) {
+                const int row = g->rowidx[k], pos = g->csc2csr[k] - indptr[row];
+                ev[(size_t)(k - g->colptr[j]) * n + j] = ((uint32_t)row << 8) | (uint32_t)pos;
+            }
+        rc = upload(&g->d_ell_col, ec);
+        if (rc == QLDPC_OK) rc = upload(&g->d_ell_var, ev);
+    }
     if (rc != QLDPC_OK) { qldpc_graph_destroy(g); return rc; }
     *out = g;
     return QLDPC_OK;
@@ -132,6 +145,8 @@ QLDPC_EXPORT void qldpc_graph_destroy(qldpc_graph *g) {
     (void)hipSetDevice(g->device);
     for (int32_t *p : {g->d_indptr, g->d_indices, g->d_colptr, g->d_rowidx, g->d_csc2csr, g->d_csr2csc})
         if (p) (void)hipFree(p);
+    if (g->d_ell_col) (void)hipFree(g->d_ell_col);
+    if (g->d_ell_var) (void)hipFree(g->d_ell_var);
     g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_alpha.release(); g->ws_misc.release();
     delete g;
 }

@@ -45,6 +45,10 @@ int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_f
 size_t mc_regular_cold_bytes();
 int judge_failed_launch(const qldpc_graph *g, const int32_t *d_count, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
                         const int8_t *f_dec, unsigned long long *d_tally, hipStream_t stream);
+// workgroup-per-shot kernel for large graphs (minsum_wg.hip)
+bool wg_supported(const qldpc_graph *g, double damping);
+int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
+                     double clip, int flags, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
 int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
                            const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
                            uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);

@@ -1,0 +1,158 @@
+// One-workgroup-per-shot min-sum decoder for LARGE Tanner graphs (circuit-level decoding matrices, BASELINE config 5:
+// 1008 x 8785, nnz 30672, check degree <= 35) with the whole decoder state resident in LDS.
+//
+// The per-edge messages (245 KB/shot in f64) do not fit in LDS, but a min-sum check node only ever emits two magnitudes:
+// state per check = (alpha*min1, alpha*min2, index of the first minimum, sign bits of its inputs, total sign) = 24 bytes.
+// R[e] = +-(alpha*mag) is reconstructed bit-exactly from it (kernels.py:311-314), both by the variable pass (posterior
+// V[j] = prior + sum of R in ASCENDING CHECK ORDER, kernels.py:316-320) and by the next check pass
+// (Q = clip(V[col] - R), kernels.py:323-345).  LDS: V[n] f64 + 24 B per check (95 KB for the [[144,12,12]] matrices).
+//   check pass: thread per row, ONE sweep over the row (no second pass: the compressed state is the output);
+//   variable pass: thread per column; index tables are ELL/slot-major in global memory, so a wave's index loads are
+//   contiguous.  The syndrome test of iteration k is a by-product of the sweep of iteration k+1; a workgroup that
+//   converged fetches its next shot (persistent grid), so per-shot early exit costs nothing.
+// damping != 1 needs Q_old per edge and is served by the streaming kernel instead.
+#include "common.h"
+#include "minsum_common.h"
+
+namespace qldpc {
+
+struct WgArgs {
+    int m, n, max_iter, fixed, rdeg, cdeg;
+    const int32_t *indptr;
+    const uint16_t *ell_col;
+    const uint32_t *ell_var;
+    int64_t B;
+    const int8_t *synd; const double *prior, *alpha;
+    double clip;
+    int8_t *out_err; double *out_llr; uint8_t *out_conv; int32_t *out_iter;
+    int offP, offI, offF;
+};
+
+
+__global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
+    extern __shared__ unsigned char lds[];
+    double *V = reinterpret_cast<double *>(lds);
+    double2 *SP = reinterpret_cast<double2 *>(lds + A.offP);                       // (alpha*min1, alpha*min2) per check
+    unsigned long long *SI = reinterpret_cast<unsigned long long *>(lds + A.offI); // bits 0-55 input signs, 56-62 argmin (127 = none), 63 total sign
+    int *unsat = reinterpret_cast<int *>(lds + A.offF);
+    const int m = A.m, n = A.n, max_iter = A.max_iter, tid = threadIdx.x, T = blockDim.x;
+    const double clip = A.clip;
+
+    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+        for (int j = tid; j < n; j += T) V[j] = A.prior[j];                                  // Q_{-1} = prior[col] (kernels.py:263-265)
+        if (tid < 2) unsat[tid] = 0;
+        bool done = false;
+        __syncthreads();
+        for (int it = 0; it <= max_iter; it++) {
+            // ---------------- check pass ----------------
+            if (A.fixed || !done) {
+                const double alpha = (it < max_iter) ? A.alpha[it] : 0.0;
+                for (int i = tid; i < m; i += T) {
+                    const int deg = A.indptr[i + 1] - A.indptr[i];
+                    const bool csyn = A.synd[b * m + i] & 1;
+                    double p1p = 0.0, p2p = 0.0;
+                    unsigned long long ip = 0ull;
+                    if (it > 0 && deg > 0) { const double2 t = SP[i]; p1p = t.x; p2p = t.y; ip = SI[i]; }
+                    const int argp = (int)((ip >> 56) & 127);
+                    const bool spp = (ip >> 63) & 1;
+                    bool par = csyn, sp = csyn;
+                    double min1 = INFINITY, min2 = INFINITY;
+                    int arg = 127;
+                    unsigned long long negbits = 0ull;
+                    for (int k = 0; k < deg; k++) {
+                        const int col = A.ell_col[(size_t)k * m + i];
+                        const double v = V[col];
+                        par ^= (v < 0.0);                                                    // kernels.py:349,356
+                        double x = v;
+                        if (it > 0) {
+                            const double mag = (k == argp) ? p2p : p1p;                      // kernels.py:313
+                            const double r = (spp != (bool)((ip >> k) & 1)) ? -mag : mag;    // R_{it-1}[e], kernels.py:311-314
+                            x = clip_nan(v - r, clip);                                       // kernels.py:325-333
+                        }
+                        const bool neg = !(x >= 0.0);                                        // kernels.py:296-299
+                        sp ^= neg;
+                        negbits |= (unsigned long long)neg << k;
+                        const double a = fabs(x);
+                        if (a < min1) { min2 = min1; min1 = a; arg = k; }                    // kernels.py:301-306
+                        else if (a < min2) { min2 = a; }
+                    }
+                    if (it >= 1 && !done && par) unsat[it & 1] = 1;                          // kernels.py:357-359
+                    if (it < max_iter && deg > 0) {                                          // kernels.py:285-286
+                        SP[i] = make_double2(alpha * min1, alpha * min2);
+                        SI[i] = negbits | ((unsigned long long)arg << 56) | ((unsigned long long)sp << 63);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---------------- freeze test (kernels.py:361-364) ----------------
+            if (!done) {
+                const bool conv = (it >= 1) && (unsat[it & 1] == 0);
+                if (conv || it == max_iter) {
+                    done = true;
+                    for (int j = tid; j < n; j += T) {
+                        const double x = (it >= 1) ? V[j] : 0.0;                             // V still holds values_{it-1}
+                        A.out_llr[b * n + j] = x;
+                        A.out_err[b * n + j] = (x < 0.0) ? 1 : 0;                            // kernels.py:349
+                    }
+                    if (tid == 0) { A.out_conv[b] = conv ? 1 : 0; A.out_iter[b] = conv ? it - 1 : max_iter - 1; }   // kernels.py:267,362
+                }
+            }
+            if (done && !A.fixed) break;                                                     // uniform: every thread read the same flag
+            if (it == max_iter) break;
+            if (tid == 0) unsat[(it + 1) & 1] = 0;
+            // ---------------- variable pass: values_it ----------------
+            for (int j = tid; j < n; j += T) {
+                double s = 0.0;                                                              // kernels.py:279
+                for (int d = 0; d < A.cdeg; d++) {
+                    const uint32_t e = A.ell_var[(size_t)d * n + j];
+                    if (e == 0xFFFFFFFFu) break;
+                    const int i = (int)(e >> 8), k = (int)(e & 255u);
+                    const double2 pp = SP[i];
+                    const unsigned long long inf = SI[i];
+                    const double mag = (k == (int)((inf >> 56) & 127)) ? pp.y : pp.x;
+                    s += ((bool)((inf >> 63) & 1) != (bool)((inf >> k) & 1)) ? -mag : mag;   // kernels.py:316, ascending check order
+                }
+                V[j] = s + A.prior[j];                                                       // kernels.py:320
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
+static size_t wg_lds_bytes(const qldpc_graph *g, int &offP, int &offI, int &offF) {
+    offP = (int)round_up((int64_t)g->n * 8, 16);
+    offI = offP + g->m * 16;
+    offF = offI + g->m * 8;
+    return (size_t)offF + 16;
+}
+
+bool wg_supported(const qldpc_graph *g, double damping) {
+    if (damping != 1.0 || !g->d_ell_col || !g->d_ell_var) return false;
+    if (g->m <= 0 || g->n <= 0 || g->max_row_deg > 56) return false;
+    int a, b, c;
+    return wg_lds_bytes(g, a, b, c) <= 160 * 1024;
+}
+
+int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
+                     double clip, int flags, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
+    WgArgs A;
+    A.m = g->m; A.n = g->n; A.max_iter = max_iter; A.fixed = (flags & QLDPC_FLAG_FIXED_ITERS) ? 1 : 0;
+    A.rdeg = g->max_row_deg; A.cdeg = g->max_col_deg;
+    A.indptr = g->d_indptr; A.ell_col = g->d_ell_col; A.ell_var = g->d_ell_var;
+    A.B = B; A.synd = d_synd; A.prior = d_prior; A.alpha = d_alpha; A.clip = clip;
+    A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;
+    const size_t lds = wg_lds_bytes(g, A.offP, A.offI, A.offF);
+    static bool attr_set = false;
+    if (!attr_set) {
+        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(minsum_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int block = (g->m > 512 || g->n > 4096) ? 1024 : 512;
+    const unsigned grid = (unsigned)std::min<int64_t>(B, 256 * 2);
+    hipLaunchKernelGGL(minsum_wg_kernel, dim3(grid), dim3(block), lds, stream, A);
+    QLDPC_HIP_TRY(hipGetLastError());
+    return QLDPC_OK;
+}
+
+}  // namespace qldpc

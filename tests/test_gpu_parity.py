@@ -87,8 +87,14 @@ def test_circuit_level_golden(L, golden, oracle, tag):
         ip, ix = data[f"Hdec{s}_indptr"], data[f"Hdec{s}_indices"]
         m, n = (int(x) for x in data[f"Hdec{s}_shape"])
         graph = L.Graph(ip, ix, n)
-        out = decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), 0)   # auto -> streaming kernel
-        check(out, g, s)
+        for fl in (0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM):      # auto = workgroup-per-shot kernel; streaming kernel forced
+            check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), fl), g, s)
+        rng = np.random.default_rng(5)                                 # ragged random batch, both kernels, vs the oracle
+        synd = (rng.random((37, m)) < 0.1).astype(np.int8)
+        ref = oracle.minsum_decode_batch(ip, ix, n, synd, g[f"llrs_{s}"], max_iter=12, threads=0)
+        for fl in (0, L.FLAG_KERNEL_STREAM):
+            for a, b in zip(decode(L, graph, synd, g[f"llrs_{s}"], 12, fl), ref):
+                assert np.array_equal(a, b, equal_nan=True)
         H = sp.csr_matrix((np.ones(ix.size, np.int8), ix, ip), shape=(m, n))
         for t, case in enumerate(g[f"{s}_osd_cases"]):
             sol = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0,
