@@ -79,4 +79,5 @@ struct qldpc_graph {
     // workspace cache for the decode kernels (guarded by mu; one decode at a time per graph handle)
     mutable std::mutex mu;
     mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_alpha, ws_misc;
+    mutable int gf2_rank = -1;       // rank of H over GF(2), computed on first OSD use
 };

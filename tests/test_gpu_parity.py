@@ -105,6 +105,22 @@ def test_circuit_level_golden(L, golden, oracle, tag):
             ref2 = oracle.osd0(ip, ix, n, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case])
             assert np.array_equal(sol2, ref2)
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
+            # the general global-memory OSD kernel (used when m > 1024) must agree with the LDS-resident one
+            os.environ["QLDPC_OSD_GLOBAL"] = "1"
+            try:
+                sol3 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0)
+                sol4 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0,
+                                           ordering=g[f"{s}_osd_ordering"][t])
+            finally:
+                del os.environ["QLDPC_OSD_GLOBAL"]
+            assert np.array_equal(sol3, ref2) and np.array_equal(sol4, g[f"{s}_osd_solution"][t])
+        # OSD-0 on arbitrary (also inconsistent) inputs: random syndromes / llrs with heavy ties / hard decisions
+        rng2 = np.random.default_rng(11)
+        for trial in range(3):
+            sy = (rng2.random(m) < 0.3).astype(np.int8)
+            ll = np.round(rng2.normal(0, 2, n), 1 if trial else 0)          # many exact ties, zeros
+            hd = (rng2.random(n) < 0.05).astype(np.int8)
+            assert np.array_equal(performOSD_enhanced(H, sy, ll, hd, order=0), oracle.osd0(ip, ix, n, sy, ll, hd)), (tag, s, trial)
 
 
 @pytest.mark.parametrize("kern", ["regular", "generic", "stream"])
