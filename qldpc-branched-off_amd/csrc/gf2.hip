@@ -357,19 +357,25 @@ QLDPC_EXPORT int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t 
 //   * pivot = the candidate row at the smallest CURRENT position >= `row` (the reference's physical row order after its
 //     swaps, kernels.py:71-82, is tracked by a position table instead of moving data);
 //   * eliminating the other ones of the column is "U[q] ^= mask for every q with bit pivot set" and b ^= mask if b[pivot];
-//   * columns are produced lazily in chunks of the K most reliable-to-flip ones (radix select + bitonic sort in LDS)
-//     and the sweep stops as soon as rank(H) pivots exist -- later columns cannot pivot.
+//   * the order (ascending |llr|, ties by index) comes from ONE bitonic sort of all columns done in the LDS that later
+//     holds U; it is parked in global memory and streamed back in chunks of K columns;
+//   * measured on the circuit-level matrices, full rank is only reached ~6,400 columns deep while only ~940 of them
+//     pivot.  A column that is dependent on the pivots so far stays dependent, so whenever the sweep meets a dependent
+//     column it tests ALL remaining columns of the chunk in parallel (one thread per column) and drops every dependent
+//     one at once; the sweep stops as soon as rank(H) pivots exist.
 // The result (pivot columns, reduced rhs at the pivots) is identical to the reference's; tests compare solutions.
 // =====================================================================================================================
 namespace qldpc {
 
 struct OsdLdsArgs {
-    int m, n, mw, rankH, K;
+    int m, n, mw, rankH, K, cdeg, npad, nokill;
     const int32_t *indptr, *indices, *colptr, *rowidx;
     const int32_t *list, *count;
     const int8_t *synd; const double *llr; const int8_t *hard; const int32_t *ordering;
     int8_t *solution;
-    int offKey, offIdx, offPhys, offPos, offPr, offPc, offRc, offB, offHist, offMisc, offScan;
+    uint16_t *ordws;               // [grid][n] sorted column order of the shot in flight (global, L2-resident)
+    unsigned long long *dbg;       // optional counters: [0] shots, [1] chunks, [2] columns swept, [3] pivots, [4] cycles, [5] kill passes
+    int offIdx, offAlive, offRows, offPhys, offPos, offPr, offPc, offRc, offB, offNp, offMisc;
 };
 
 __device__ __forceinline__ unsigned long long osd_key(double x) {
@@ -377,21 +383,23 @@ __device__ __forceinline__ unsigned long long osd_key(double x) {
     if (a != a) a = INFINITY;
     return (unsigned long long)__double_as_longlong(a);          // non-negative doubles order like their bit patterns
 }
-__device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ (q & 15)) : w); }
+template <int MW> __device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((MW == 16) ? (w ^ (q & 15)) : w); }
 
+template <int MW>
 __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     extern __shared__ unsigned char lds[];
-    const int m = P.m, n = P.n, mw = P.mw, K = P.K, tid = threadIdx.x, T = blockDim.x;
+    const int m = P.m, n = P.n, mw = (MW > 0) ? MW : P.mw, K = P.K, cd = P.cdeg, tid = threadIdx.x, T = blockDim.x;
     unsigned long long *U = reinterpret_cast<unsigned long long *>(lds);
-    unsigned long long *skey = reinterpret_cast<unsigned long long *>(lds + P.offKey);
-    uint16_t *sidx = reinterpret_cast<uint16_t *>(lds + P.offIdx);
+    uint16_t *sidx = reinterpret_cast<uint16_t *>(lds + P.offIdx);         // [K] columns of the current chunk
+    uint8_t *alive = reinterpret_cast<uint8_t *>(lds + P.offAlive);        // [K]
+    uint16_t *colrows = reinterpret_cast<uint16_t *>(lds + P.offRows);     // [K][cd] supports
     uint16_t *phys = reinterpret_cast<uint16_t *>(lds + P.offPhys), *pos_of = reinterpret_cast<uint16_t *>(lds + P.offPos);
     uint16_t *pvrow = reinterpret_cast<uint16_t *>(lds + P.offPr), *pvcol = reinterpret_cast<uint16_t *>(lds + P.offPc);
     unsigned long long *rc = reinterpret_cast<unsigned long long *>(lds + P.offRc);
     unsigned long long *bvec = reinterpret_cast<unsigned long long *>(lds + P.offB);
-    unsigned int *hist = reinterpret_cast<unsigned int *>(lds + P.offHist);
-    unsigned int *misc = reinterpret_cast<unsigned int *>(lds + P.offMisc);     // [0] best, [1] compaction counter, [2..7] select state
-    unsigned int *scan = reinterpret_cast<unsigned int *>(lds + P.offScan);     // [T] tie counts
+    unsigned long long *npm = reinterpret_cast<unsigned long long *>(lds + P.offNp);   // mask of rows that are not pivots yet
+    unsigned int *misc = reinterpret_cast<unsigned int *>(lds + P.offMisc);
+    uint16_t *ordw = P.ordws + (size_t)blockIdx.x * n;
 
     const int total = *P.count;
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
@@ -399,147 +407,136 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         const double *llr = P.llr + shot * n;
         const int8_t *hard = P.hard + shot * n, *synd = P.synd + shot * m;
         int8_t *sol = P.solution + shot * n;
+        const long long t_start = clock64();
+        // ---- column order: ascending |llr| (osd.py:11-12), ties by ascending index; bitonic sort of (key, index) in LDS ----
+        if (!P.ordering) {
+            unsigned long long *keys = reinterpret_cast<unsigned long long *>(lds);                 // [n]   (aliases U)
+            uint16_t *perm = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8);                     // [npad]
+            const int npad = P.npad;
+            for (int j = tid; j < n; j += T) keys[j] = osd_key(llr[j]);
+            for (int j = tid; j < npad; j += T) perm[j] = (j < n) ? (uint16_t)j : (uint16_t)0xFFFF;
+            __syncthreads();
+            for (int size = 2; size <= npad; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = tid; t < (npad >> 1); t += T) {
+                        const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), p = i | stride;
+                        const uint16_t ia = perm[i], ib = perm[p];
+                        const unsigned long long ka = (ia == 0xFFFF) ? ~0ull : keys[ia], kb = (ib == 0xFFFF) ? ~0ull : keys[ib];
+                        const bool gt = (ka > kb) || (ka == kb && ia > ib);
+                        if (gt == ((i & size) == 0)) { perm[i] = ib; perm[p] = ia; }
+                    }
+                    __syncthreads();
+                }
+            for (int j = tid; j < n; j += T) ordw[j] = perm[j];
+            __syncthreads();
+        }
         // ---- init: T = I, positions = identity, b = s + H hard (osd.py:8-9) ----
         for (int t = tid; t < m * mw; t += T) U[t] = 0ull;
-        for (int w = tid; w < mw; w += T) bvec[w] = 0ull;
+        for (int w = tid; w < mw; w += T) { bvec[w] = 0ull; npm[w] = 0ull; }
         __syncthreads();
         for (int r = tid; r < m; r += T) {
-            U[uswz(r, r >> 6, mw)] = 1ull << (r & 63);
+            U[uswz<MW>(r, r >> 6, mw)] = 1ull << (r & 63);
             phys[r] = (uint16_t)r; pos_of[r] = (uint16_t)r;
+            atomicOr(&npm[r >> 6], 1ull << (r & 63));
             int s = synd[r] & 1;
             for (int e = P.indptr[r]; e < P.indptr[r + 1]; e++) s ^= hard[P.indices[e]] & 1;
             if (s) atomicOr(&bvec[r >> 6], 1ull << (r & 63));
         }
         __syncthreads();
-        int row = 0, npiv = 0, chunk_base = 0;
-        unsigned long long last_key = 0ull;
-        int last_idx = -1;
-        bool finished = false;
-        while (!finished) {
-            // ================= next chunk of columns in reliability order =================
-            int L = 0;
-            if (P.ordering) {
-                L = min(K, n - chunk_base);
-                for (int c = tid; c < L; c += T) sidx[c] = (uint16_t)P.ordering[shot * n + chunk_base + c];
-                chunk_base += L;
-                __syncthreads();
-            } else {
-                // eligible(j): (key_j, j) > (last_key, last_idx).  Select the K smallest, sort them by (key, index).
-                if (tid == 0) { misc[1] = 0; misc[2] = 0; }
-                __syncthreads();
-                unsigned int elig = 0;
-                for (int j = tid; j < n; j += T) {
-                    const unsigned long long k = osd_key(llr[j]);
-                    elig += (k > last_key || (k == last_key && j > last_idx)) ? 1u : 0u;
-                }
-                if (elig) atomicAdd(&misc[2], elig);
-                __syncthreads();
-                const unsigned int E = misc[2];
-                unsigned long long thr_key = ~0ull;        // take keys < thr_key entirely, and `need` ties with key == thr_key
-                unsigned int need = 0;
-                if (E > (unsigned)K) {
-                    unsigned long long prefix = 0ull, pmask = 0ull;
-                    unsigned int want = (unsigned)K;
-                    for (int pass = 7; pass >= 0; pass--) {
-                        for (int d = tid; d < 256; d += T) hist[d] = 0;
-                        __syncthreads();
-                        for (int j = tid; j < n; j += T) {
-                            const unsigned long long k = osd_key(llr[j]);
-                            if ((k > last_key || (k == last_key && j > last_idx)) && (k & pmask) == prefix) atomicAdd(&hist[(k >> (8 * pass)) & 255], 1u);
-                        }
-                        __syncthreads();
-                        if (tid == 0) {
-                            unsigned int cum = 0, d = 0;
-                            for (; d < 255; d++) { if (cum + hist[d] >= want) break; cum += hist[d]; }
-                            misc[3] = d; misc[4] = cum;
-                        }
-                        __syncthreads();
-                        prefix |= (unsigned long long)misc[3] << (8 * pass);
-                        pmask |= 255ull << (8 * pass);
-                        want -= misc[4];
-                        __syncthreads();
-                    }
-                    thr_key = prefix; need = want;
-                }
-                // compaction: keys below the threshold in any order, ties in ascending index order
-                for (int c = tid; c < K; c += T) { skey[c] = ~0ull; sidx[c] = 0xFFFF; }
-                __syncthreads();
-                const int per = (n + T - 1) / T, j0 = tid * per, j1 = min(n, j0 + per);
-                unsigned int myties = 0;
-                for (int j = j0; j < j1; j++) {
-                    const unsigned long long k = osd_key(llr[j]);
-                    if (!(k > last_key || (k == last_key && j > last_idx))) continue;
-                    if (k < thr_key) { const unsigned int s = atomicAdd(&misc[1], 1u); skey[s] = k; sidx[s] = (uint16_t)j; }
-                    else if (k == thr_key) myties++;
-                }
-                scan[tid] = myties;
-                __syncthreads();
-                if (E > (unsigned)K) {
-                    if (tid == 0) { unsigned int run = 0; for (int t = 0; t < T; t++) { const unsigned int c = scan[t]; scan[t] = run; run += c; } }
-                    __syncthreads();
-                    unsigned int rank = scan[tid];
-                    const unsigned int base = misc[1];          // number of keys below the threshold (= K - need)
-                    for (int j = j0; j < j1 && rank < need; j++) {
-                        const unsigned long long k = osd_key(llr[j]);
-                        if ((k > last_key || (k == last_key && j > last_idx)) && k == thr_key) { skey[base + rank] = k; sidx[base + rank] = (uint16_t)j; rank++; }
-                    }
-                }
-                __syncthreads();
-                L = (int)min(E, (unsigned)K);
-                // bitonic sort of the K slots by (key, index); empty slots (key ~0, index 0xFFFF) sink to the end
-                for (int size = 2; size <= K; size <<= 1)
-                    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                        for (int i = tid; i < K; i += T) {
-                            const int p = i ^ stride;
-                            if (p > i) {
-                                const unsigned long long ka = skey[i], kb = skey[p];
-                                const uint16_t ia = sidx[i], ib = sidx[p];
-                                const bool gt = (ka > kb) || (ka == kb && ia > ib);
-                                if (gt == ((i & size) == 0)) { skey[i] = kb; skey[p] = ka; sidx[i] = ib; sidx[p] = ia; }
-                            }
-                        }
-                        __syncthreads();
-                    }
-                if (L > 0) { last_key = skey[L - 1]; last_idx = sidx[L - 1]; }
-                __syncthreads();
+        int row = 0, npiv = 0;
+        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0;
+        bool finished = (P.rankH == 0);
+        for (int base = 0; base < n && !finished; base += K) {
+            const int L = min(K, n - base);
+            d_chunks++;
+            for (int c = tid; c < L; c += T) {
+                sidx[c] = P.ordering ? (uint16_t)P.ordering[shot * n + base + c] : ordw[base + c];
+                alive[c] = 1;
             }
-            if (L == 0) break;
-            // ================= sweep the chunk (kernels.py:64-94 on the reduced sparse columns) =================
+            __syncthreads();
+            for (int t = tid; t < L * cd; t += T) {                          // supports of the chunk's columns -> LDS
+                const int c = t / cd, d = t - c * cd, j = sidx[c];
+                const int k = P.colptr[j] + d;
+                colrows[t] = (k < P.colptr[j + 1]) ? (uint16_t)P.rowidx[k] : (uint16_t)0xFFFF;
+            }
+            if (tid < 3) misc[8 + tid] = 0xFFFFFFFFu;
+            __syncthreads();
+            // ================= sweep (kernels.py:64-94 on the reduced sparse columns) =================
+            int step = 0;
             for (int c = 0; c < L; c++) {
-                const int j = sidx[c];
-                if (tid < mw) {
+                if (!alive[c]) continue;                                     // uniform: every thread reads the same byte
+                const bool marked = (alive[c] == 2);
+                const uint16_t *cr = colrows + c * cd;
+                unsigned int *bestp = &misc[8 + step % 3];
+                d_cols++;
+                if (tid < mw) {                                              // reduced column T h, kept for the elimination
                     unsigned long long w = 0ull;
-                    for (int k = P.colptr[j]; k < P.colptr[j + 1]; k++) w ^= U[uswz(P.rowidx[k], tid, mw)];
+                    for (int d = 0; d < cd; d++) { const int i = cr[d]; if (i != 0xFFFF) w ^= U[uswz<MW>(i, tid, mw)]; }
                     rc[tid] = w;
                 }
-                unsigned int *bestp = &misc[8 + (c & 1)];         // two slots: a fast thread may already reset the next column's slot
-                if (tid == 0) *bestp = 0xFFFFFFFFu;
-                __syncthreads();
-                for (int r = tid; r < m; r += T)
-                    if (((rc[r >> 6] >> (r & 63)) & 1ull) && pos_of[r] >= row) atomicMin(bestp, ((unsigned int)pos_of[r] << 16) | (unsigned int)r);
+                for (int r = tid; r < m; r += T) {
+                    if (pos_of[r] < row) continue;                           // already a pivot row
+                    unsigned long long w = 0ull;
+                    for (int d = 0; d < cd; d++) { const int i = cr[d]; if (i != 0xFFFF) w ^= U[uswz<MW>(i, r >> 6, mw)]; }
+                    if ((w >> (r & 63)) & 1ull) atomicMin(bestp, ((unsigned int)pos_of[r] << 16) | (unsigned int)r);   // kernels.py:71-75
+                }
                 __syncthreads();
                 const unsigned int best = *bestp;
+                if (tid == 0) misc[8 + (step + 2) % 3] = 0xFFFFFFFFu;        // slot used two steps from now
+                step++;
+                if (marked && best != 0xFFFFFFFFu && P.dbg && tid == 0) atomicAdd(&P.dbg[6], 1ull);     // a "dependent" column has a candidate
                 if (best != 0xFFFFFFFFu) {
                     const int pr = (int)(best & 0xFFFFu), ppos = (int)(best >> 16);
                     const unsigned long long prbit = 1ull << (pr & 63);
                     const int prw = pr >> 6;
                     const bool bpr = (bvec[prw] & prbit) != 0ull;
-                    for (int q = tid; q < m; q += T)                                          // rows with a one in this column get the pivot row added
-                        if (U[uswz(q, prw, mw)] & prbit)
-                            for (int w = 0; w < mw; w++) U[uswz(q, w, mw)] ^= (w == prw) ? (rc[w] & ~prbit) : rc[w];
-                    __syncthreads();
-                    if (tid < mw && bpr) bvec[tid] ^= (tid == prw) ? (rc[tid] & ~prbit) : rc[tid];
-                    if (tid == 0) {
+                    for (int q = tid; q < m; q += T)                         // rows with a one in this column get the pivot row added
+                        if (U[uswz<MW>(q, prw, mw)] & prbit) {
+                            if (MW > 0) {
+#pragma unroll
+                                for (int w = 0; w < (MW > 0 ? MW : 1); w++) U[uswz<MW>(q, w, mw)] ^= (w == prw) ? (rc[w] & ~prbit) : rc[w];
+                            } else {
+                                for (int w = 0; w < mw; w++) U[uswz<MW>(q, w, mw)] ^= (w == prw) ? (rc[w] & ~prbit) : rc[w];
+                            }
+                        }
+                    if (tid < mw && bpr) bvec[tid] ^= (tid == prw) ? (rc[tid] & ~prbit) : rc[tid];     // bit pr itself never changes
+                    if (tid == 0) {                                          // the reference's row swap (kernels.py:79-82) as positions
                         const int r0 = phys[row];
                         phys[row] = (uint16_t)pr; phys[ppos] = (uint16_t)r0; pos_of[pr] = (uint16_t)row; pos_of[r0] = (uint16_t)ppos;
-                        pvrow[npiv] = (uint16_t)pr; pvcol[npiv] = (uint16_t)j;
+                        pvrow[npiv] = (uint16_t)pr; pvcol[npiv] = sidx[c];
+                        npm[prw] &= ~prbit;
                     }
                     row++; npiv++;
                     __syncthreads();
                     if (row >= P.rankH || row >= m) { finished = true; break; }
+                } else {
+                    // column c depends on the pivots so far.  So may many of the columns behind it: test them all at once.
+                    d_kills++;
+                    for (int c2 = c + 1 + tid; c2 < L && P.nokill != 1; c2 += T) {
+                        if (!alive[c2]) continue;
+                        const uint16_t *cr2 = colrows + c2 * cd;
+                        unsigned long long any = 0ull;
+                        for (int w = 0; w < mw; w++) {
+                            unsigned long long x = 0ull;
+                            for (int d = 0; d < cd; d++) { const int i = cr2[d]; if (i != 0xFFFF) x ^= U[uswz<MW>(i, w, mw)]; }
+                            any |= x & npm[w];
+                        }
+                        if (!any) alive[c2] = (P.nokill == 2) ? 2 : 0;
+                    }
+                    if (P.nokill == 2 && P.dbg) {       // cross-check the non-pivot mask against the position table
+                        for (int r = tid; r < m; r += T) {
+                            const bool np1 = (npm[r >> 6] >> (r & 63)) & 1ull, np2 = pos_of[r] >= row;
+                            if (np1 != np2) atomicAdd(&P.dbg[7], 1ull);
+                        }
+                    }
+                    __syncthreads();
                 }
             }
-            if (L < K || (P.ordering && chunk_base >= n)) finished = true;
+            __syncthreads();      // the tail of a chunk may be all skipped columns: nobody may refill alive[]/sidx[] while others still scan it
+        }
+        if (P.dbg && tid == 0) {
+            atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)npiv);
+            atomicAdd(&P.dbg[4], (unsigned long long)(clock64() - t_start)); atomicAdd(&P.dbg[5], d_kills);
         }
         // ---- back-fill (osd.py:19-25): e[pivot col] = reduced rhs at the pivot row; solution = (hard + e) % 2 ----
         __syncthreads();
@@ -576,19 +573,22 @@ static int host_rank(const qldpc_graph *g) {
 
 static bool plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
     if (g->m > 1024 || g->n >= 65535 || g->m < 1) return false;
-    P.m = g->m; P.n = g->n; P.mw = (g->m + 63) / 64; P.K = 1024;
-    size_t off = (size_t)g->m * P.mw * 8;
-    P.offKey = (int)off; off += (size_t)P.K * 8;
+    P.m = g->m; P.n = g->n; P.mw = (g->m + 63) / 64; P.K = 1024; P.cdeg = std::max(g->max_col_deg, 1);
+    P.npad = 1;
+    while (P.npad < g->n) P.npad <<= 1;
+    size_t off = std::max((size_t)g->m * P.mw * 8, (size_t)g->n * 8 + (size_t)P.npad * 2);     // U, aliased by the sort scratch
+    off = (size_t)round_up((int64_t)off, 16);
     P.offIdx = (int)off; off += (size_t)P.K * 2;
-    P.offPhys = (int)off; off += round_up((size_t)g->m * 2, 8);
-    P.offPos = (int)off; off += round_up((size_t)g->m * 2, 8);
-    P.offPr = (int)off; off += round_up((size_t)g->m * 2, 8);
-    P.offPc = (int)off; off += round_up((size_t)g->m * 2, 8);
+    P.offAlive = (int)off; off += (size_t)P.K;
+    P.offRows = (int)off; off += (size_t)P.K * P.cdeg * 2;
+    P.offPhys = (int)off; off += round_up((int64_t)g->m * 2, 8);
+    P.offPos = (int)off; off += round_up((int64_t)g->m * 2, 8);
+    P.offPr = (int)off; off += round_up((int64_t)g->m * 2, 8);
+    P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
     P.offRc = (int)off; off += (size_t)P.mw * 8;
     P.offB = (int)off; off += (size_t)P.mw * 8;
-    P.offHist = (int)off; off += 256 * 4;
+    P.offNp = (int)off; off += (size_t)P.mw * 8;
     P.offMisc = (int)off; off += 64;
-    P.offScan = (int)off; off += 1024 * 4;
     lds = off + 16;
     return lds <= 160 * 1024;
 }
@@ -601,15 +601,35 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     if (getenv("QLDPC_OSD_GLOBAL") || !plan_osd_lds(g, P, lds)) return QLDPC_OK;
     if (g->gf2_rank < 0) g->gf2_rank = host_rank(g);      // callers hold g->mu
     P.rankH = g->gf2_rank;
+    const int grid = 512;
+    int rc = g->ws_misc.ensure((size_t)grid * g->n * 2 + 64);
+    if (rc != QLDPC_OK) return rc;
+    P.ordws = g->ws_misc.as<uint16_t>();
     P.indptr = g->d_indptr; P.indices = g->d_indices; P.colptr = g->d_colptr; P.rowidx = g->d_rowidx;
     P.list = d_list; P.count = d_count; P.synd = d_synd; P.llr = d_llr; P.hard = d_hard; P.ordering = d_ordering; P.solution = d_solution;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    static unsigned long long *d_dbg = nullptr;
+    P.dbg = nullptr;
+    if (getenv("QLDPC_OSD_DEBUG")) {
+        if (!d_dbg) { QLDPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_dbg), 64)); QLDPC_HIP_TRY(hipMemset(d_dbg, 0, 64)); }
+        else {
+            unsigned long long h[8];
+            QLDPC_HIP_TRY(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));      // counters of the previous launches
+            if (h[0]) fprintf(stderr, "[osd dbg] shots=%llu chunks/shot=%.2f cols/shot=%.1f pivots/shot=%.1f kills/shot=%.1f kcycles/shot=%.1f rankH=%d viol=%llu maskdiff=%llu\n",
+                              h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[5] / h[0], (double)h[4] / h[0] / 1e3, g->gf2_rank, h[6], h[7]);
+        }
+        P.dbg = d_dbg;
     }
     const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m, 256), 64));
-    hipLaunchKernelGGL(osd0_lds_kernel, dim3(512), dim3(block), lds, stream, P);
+    P.nokill = getenv("QLDPC_OSD_NOKILL") ? atoi(getenv("QLDPC_OSD_NOKILL")) : 0;
+    if (P.mw == 16 && !getenv("QLDPC_OSD_GENERIC")) {
+        static bool a16 = false;
+        if (!a16) { QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a16 = true; }
+        hipLaunchKernelGGL(osd0_lds_kernel<16>, dim3(grid), dim3(block), lds, stream, P);
+    } else {
+        static bool a0 = false;
+        if (!a0) { QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a0 = true; }
+        hipLaunchKernelGGL(osd0_lds_kernel<0>, dim3(grid), dim3(block), lds, stream, P);
+    }
     QLDPC_HIP_TRY(hipGetLastError());
     handled = true;
     return QLDPC_OK;

@@ -241,9 +241,12 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
             hipLaunchKernelGGL(collect_failed_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, P->d_conv.as<uint8_t>(),
                                P->d_list.as<int32_t>(), P->d_count.as<int32_t>());
             QLDPC_HIP_TRY(hipGetLastError());
-            if ((rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), P->d_synd.as<int8_t>(),
-                                         P->d_llr.as<double>(), P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), s)) != QLDPC_OK)
-                return rc;
+            {
+                std::lock_guard<std::mutex> lk(g->mu);
+                rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), P->d_synd.as<int8_t>(), P->d_llr.as<double>(),
+                                        P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), s);
+            }
+            if (rc != QLDPC_OK) return rc;
             hipLaunchKernelGGL(add_osd_count_kernel, dim3(1), dim3(64), 0, s, P->d_count.as<int32_t>(),
                                P->d_tally.as<unsigned long long>());
         }
