@@ -431,7 +431,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
             __syncthreads();
         }
         // ---- init: T = I, positions = identity, b = s + H hard (osd.py:8-9) ----
-        for (int t = tid; t < m * mw; t += T) U[t] = 0ull;
+        for (int t = tid; t < (m + 1) * mw; t += T) U[t] = 0ull;          // row m stays zero: padding target of short columns
         for (int w = tid; w < mw; w += T) { bvec[w] = 0ull; npm[w] = 0ull; }
         __syncthreads();
         for (int r = tid; r < m; r += T) {
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
             for (int t = tid; t < L * cd; t += T) {                          // supports of the chunk's columns -> LDS
                 const int c = t / cd, d = t - c * cd, j = sidx[c];
                 const int k = P.colptr[j] + d;
-                colrows[t] = (k < P.colptr[j + 1]) ? (uint16_t)P.rowidx[k] : (uint16_t)0xFFFF;
+                colrows[t] = (k < P.colptr[j + 1]) ? (uint16_t)P.rowidx[k] : (uint16_t)m;          // row m of U is all zero
             }
             if (tid < 3) misc[8 + tid] = 0xFFFFFFFFu;
             __syncthreads();
@@ -469,15 +469,28 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 const uint16_t *cr = colrows + c * cd;
                 unsigned int *bestp = &misc[8 + step % 3];
                 d_cols++;
+                int ci[8];                                                   // the column's support (<= 8 rows kept in registers)
+#pragma unroll
+                for (int d = 0; d < 8; d++) ci[d] = (d < cd) ? cr[d] : m;
                 if (tid < mw) {                                              // reduced column T h, kept for the elimination
                     unsigned long long w = 0ull;
-                    for (int d = 0; d < cd; d++) { const int i = cr[d]; if (i != 0xFFFF) w ^= U[uswz<MW>(i, tid, mw)]; }
+                    if (cd <= 8) {
+#pragma unroll
+                        for (int d = 0; d < 8; d++) w ^= U[uswz<MW>(ci[d], tid, mw)];
+                    } else {
+                        for (int d = 0; d < cd; d++) w ^= U[uswz<MW>(cr[d], tid, mw)];
+                    }
                     rc[tid] = w;
                 }
                 for (int r = tid; r < m; r += T) {
                     if (pos_of[r] < row) continue;                           // already a pivot row
                     unsigned long long w = 0ull;
-                    for (int d = 0; d < cd; d++) { const int i = cr[d]; if (i != 0xFFFF) w ^= U[uswz<MW>(i, r >> 6, mw)]; }
+                    if (cd <= 8) {
+#pragma unroll
+                        for (int d = 0; d < 8; d++) w ^= U[uswz<MW>(ci[d], r >> 6, mw)];
+                    } else {
+                        for (int d = 0; d < cd; d++) w ^= U[uswz<MW>(cr[d], r >> 6, mw)];
+                    }
                     if ((w >> (r & 63)) & 1ull) atomicMin(bestp, ((unsigned int)pos_of[r] << 16) | (unsigned int)r);   // kernels.py:71-75
                 }
                 __syncthreads();
@@ -503,6 +516,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     if (tid == 0) {                                          // the reference's row swap (kernels.py:79-82) as positions
                         const int r0 = phys[row];
                         phys[row] = (uint16_t)pr; phys[ppos] = (uint16_t)r0; pos_of[pr] = (uint16_t)row; pos_of[r0] = (uint16_t)ppos;
+                    } else if (tid == 64) {
                         pvrow[npiv] = (uint16_t)pr; pvcol[npiv] = sidx[c];
                         npm[prw] &= ~prbit;
                     }
@@ -516,10 +530,22 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                         if (!alive[c2]) continue;
                         const uint16_t *cr2 = colrows + c2 * cd;
                         unsigned long long any = 0ull;
-                        for (int w = 0; w < mw; w++) {
-                            unsigned long long x = 0ull;
-                            for (int d = 0; d < cd; d++) { const int i = cr2[d]; if (i != 0xFFFF) x ^= U[uswz<MW>(i, w, mw)]; }
-                            any |= x & npm[w];
+                        if (cd <= 8) {
+                            int c2i[8];
+#pragma unroll
+                            for (int d = 0; d < 8; d++) c2i[d] = (d < cd) ? cr2[d] : m;
+                            for (int w = 0; w < mw; w++) {
+                                unsigned long long x = 0ull;
+#pragma unroll
+                                for (int d = 0; d < 8; d++) x ^= U[uswz<MW>(c2i[d], w, mw)];
+                                any |= x & npm[w];
+                            }
+                        } else {
+                            for (int w = 0; w < mw; w++) {
+                                unsigned long long x = 0ull;
+                                for (int d = 0; d < cd; d++) x ^= U[uswz<MW>(cr2[d], w, mw)];
+                                any |= x & npm[w];
+                            }
                         }
                         if (!any) alive[c2] = (P.nokill == 2) ? 2 : 0;
                     }
@@ -576,7 +602,7 @@ static bool plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
     P.m = g->m; P.n = g->n; P.mw = (g->m + 63) / 64; P.K = 1024; P.cdeg = std::max(g->max_col_deg, 1);
     P.npad = 1;
     while (P.npad < g->n) P.npad <<= 1;
-    size_t off = std::max((size_t)g->m * P.mw * 8, (size_t)g->n * 8 + (size_t)P.npad * 2);     // U, aliased by the sort scratch
+    size_t off = std::max((size_t)(g->m + 1) * P.mw * 8, (size_t)g->n * 8 + (size_t)P.npad * 2);     // U, aliased by the sort scratch
     off = (size_t)round_up((int64_t)off, 16);
     P.offIdx = (int)off; off += (size_t)P.K * 2;
     P.offAlive = (int)off; off += (size_t)P.K;
