@@ -175,6 +175,11 @@ typedef struct {
     const uint8_t *Lx, *Lz;                             /* logical operators, dense k x n_data */
 } qldpc_circuit_desc;
 
+/* Single-fault signatures of one sector: the batched form of the per-fault simulations in src/noise/builder.py:37-66
+ * (_simulate_Z_from_spec / _simulate_X_from_spec).  Entry e = 2 * base_op_index + slot (slot 1 = CNOT target). */
+int qldpc_circuit_fault_signatures(const qldpc_circuit_desc *circuit, int sector_is_x, int32_t *ptr, uint16_t *idx, int64_t idx_cap,
+                                   uint64_t *logmask, int64_t *idx_needed);
+
 typedef struct qldpc_circuit_plan qldpc_circuit_plan;
 /* a13 + a14: run_trial_fast (src/noise/simulation.py:21-107) + _run_single_trial_fast and the tally
  * (src/simulation/engine.py:68-122, 450-457), batched.  gz / gx: Tanner graphs of HdecZ / HdecX; prior_*: LLRs of

@@ -23,7 +23,7 @@ EXPORTS = [
     "qldpc_noisy_circuit_batch", "qldpc_frame_sim_batch", "qldpc_sparsify_batch", "qldpc_cc_sample_decode_tally",
     "qldpc_cc_plan_create", "qldpc_cc_plan_run", "qldpc_cc_plan_read", "qldpc_cc_plan_kernel_time", "qldpc_cc_plan_destroy",
     "qldpc_philox4x32_10", "qldpc_circuit_plan_create", "qldpc_circuit_plan_run", "qldpc_circuit_plan_read", "qldpc_circuit_plan_sample",
-    "qldpc_circuit_plan_destroy",
+    "qldpc_circuit_plan_destroy", "qldpc_circuit_fault_signatures",
 ]
 
 
@@ -275,6 +275,38 @@ def logical_column_masks(logical_rows, n):
         for r in range(M.shape[0]):
             lm[np.flatnonzero(M[r])] |= np.uint64(1) << np.uint64(r)
     return lm
+
+
+def make_circuit_desc(compiled, Lx, Lz):
+    """CompiledCircuit-like object (or dict of its arrays) -> (CircuitDesc, keep-alive dict)."""
+    keep = {k: i32(_attr(compiled, k)) for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions",
+                                                 "x_syn_ptrs", "z_syn_positions", "z_syn_ptrs", "data_qubit_indices")}
+    keep["Lx"], keep["Lz"] = u8(Lx), u8(Lz)
+    d = CircuitDesc()
+    d.base_len, d.suffix_len = keep["base_ops"].size, keep["suffix_ops"].size
+    for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions", "x_syn_ptrs", "z_syn_positions",
+              "z_syn_ptrs", "data_qubit_indices"):
+        setattr(d, k, ptr(keep[k], C.c_int32))
+    d.total_qubits = int(_attr(compiled, "total_qubits"))
+    d.num_x_checks, d.num_z_checks = keep["x_syn_ptrs"].size - 1, keep["z_syn_ptrs"].size - 1
+    d.n_data, d.k = keep["data_qubit_indices"].size, keep["Lx"].shape[0]
+    d.Lx, d.Lz = ptr(keep["Lx"], C.c_uint8), ptr(keep["Lz"], C.c_uint8)
+    return d, keep
+
+
+def circuit_fault_signatures(compiled, Lx, Lz, sector_is_x):
+    """(ptr int32[2*L+1], idx uint16[...], logmask uint64[2*L]) of every single-qubit flip at every base-circuit location."""
+    require_device()
+    d, keep = make_circuit_desc(compiled, Lx, Lz)
+    L = keep["base_ops"].size
+    sp = np.zeros(2 * L + 1, np.int32)
+    lm = np.zeros(2 * L, np.uint64)
+    cap = max(1024, 64 * 2 * L)
+    idx = np.zeros(cap, np.uint16)
+    need = C.c_int64(0)
+    check(lib().qldpc_circuit_fault_signatures(C.byref(d), C.c_int(int(sector_is_x)), ptr(sp, C.c_int32), ptr(idx, C.c_uint16), C.c_int64(cap),
+                                               ptr(lm, C.c_uint64), C.byref(need)))
+    return sp, idx[:need.value].copy(), lm
 
 
 class CircuitPlan:

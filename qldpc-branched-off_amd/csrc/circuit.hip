@@ -296,6 +296,34 @@ static int validate_desc(const qldpc_circuit_desc *D) {
     return QLDPC_OK;
 }
 
+// Single-fault signatures of one sector (what the reference's builder simulates fault by fault, src/noise/builder.py:37-66).
+// Entry e = 2 * base_op_index + slot (slot 0 = the gate's first qubit, slot 1 = the CNOT target).  ptr int32[2*base_len+1],
+// idx uint16[idx_cap] (detector indices, ascending per entry), logmask uint64[2*base_len].  *idx_needed receives the total
+// number of detector entries; QLDPC_ERR_INVALID if idx_cap is too small (call again with a larger buffer).
+QLDPC_EXPORT int qldpc_circuit_fault_signatures(const qldpc_circuit_desc *D, int sector_is_x, int32_t *ptr, uint16_t *idx, int64_t idx_cap,
+                                                uint64_t *logmask, int64_t *idx_needed) {
+    int rc = validate_desc(D);
+    if (rc != QLDPC_OK) return rc;
+    QLDPC_REQUIRE(ptr && logmask && idx_needed && (idx || idx_cap == 0), "NULL output");
+    if ((rc = use_device(0)) != QLDPC_OK) return rc;
+    std::vector<int32_t> ops(D->base_ops, D->base_ops + D->base_len), q1(D->base_q1, D->base_q1 + D->base_len), q2(D->base_q2, D->base_q2 + D->base_len);
+    ops.insert(ops.end(), D->suffix_ops, D->suffix_ops + D->suffix_len);
+    q1.insert(q1.end(), D->suffix_q1, D->suffix_q1 + D->suffix_len);
+    q2.insert(q2.end(), D->suffix_q2, D->suffix_q2 + D->suffix_len);
+    std::vector<int32_t> loc_op(D->base_len);
+    for (int64_t i = 0; i < D->base_len; i++) loc_op[i] = (int32_t)i;
+    std::vector<int32_t> p;
+    std::vector<uint16_t> ix;
+    std::vector<uint64_t> lm;
+    if ((rc = build_signatures(D, sector_is_x != 0, loc_op, ops, q1, q2, p, ix, lm)) != QLDPC_OK) return rc;
+    *idx_needed = (int64_t)ix.size();
+    QLDPC_REQUIRE((int64_t)ix.size() <= idx_cap, "idx buffer too small: need %lld entries", (long long)ix.size());
+    std::memcpy(ptr, p.data(), p.size() * sizeof(int32_t));
+    if (!ix.empty()) std::memcpy(idx, ix.data(), ix.size() * sizeof(uint16_t));
+    std::memcpy(logmask, lm.data(), lm.size() * sizeof(uint64_t));
+    return QLDPC_OK;
+}
+
 QLDPC_EXPORT int qldpc_circuit_plan_create(const qldpc_circuit_desc *D, const qldpc_graph *gz, const qldpc_graph *gx, const double *prior_z,
                                            const double *prior_x, const uint64_t *logmask_z, const uint64_t *logmask_x, double p, int max_iter,
                                            int alpha_mode, double alpha_val_z, double alpha_val_x, const double *alpha_seq_z, int alpha_len_z,

@@ -7,7 +7,6 @@ concurrently on the device (qldpc_circuit_plan_*), the tally stays on the device
 Differences that are deliberate and documented:
   * randomness comes from Philox streams keyed by (base_seed, global trial index), not from legacy ``np.random``; results
     are reproducible and independent of the number of GPUs, and statistically equivalent to the reference;
-  * ``precomputed_matrices`` is required (the decoding-matrix builder, src/noise/builder.py, is a 'next' row);
   * ``osd_order`` must be 0 (OSD-w sweep is a 'next' row); alpha estimation (alpha.py / scopt.py) is out of scope, so
     ``alpha_mode='alvarado'`` needs ``alvarado_alpha`` and ``'alvarado-autoregressive'`` is not available;
   * ``target_logical_errors`` stops at batch granularity (the reference stops at trial granularity, engine.py:462-464).
@@ -17,6 +16,7 @@ import numpy as np
 from .. import _lib, parallel
 from ..codes.bb_code import BBCodeCircuit
 from ..noise.compiled import CompiledCircuit
+from ..noise.builder import build_decoding_matrices
 
 
 def prior_llrs(channel_probs):
@@ -29,8 +29,6 @@ def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, m
                    alpha_mode=None, alvarado_alpha=None, alpha_estimation_trials=5000, alpha_estimation_bins=50, precomputed_matrices=None,
                    num_workers=None, base_seed=None, use_jit=True, target_logical_errors=None, max_trials=None, scopt=False,
                    estimation_plot_dir=None, batch=4096, device=0, **bb_params):
-    if precomputed_matrices is None:
-        raise NotImplementedError("build_decoding_matrices (src/noise/builder.py) is not part of this build yet: pass precomputed_matrices")
     if osd_order != 0:
         raise NotImplementedError("OSD-w with w > 0 is a 'next' row; use osd_order=0")
     if scopt:
@@ -53,8 +51,8 @@ def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, m
     else:
         raise ValueError(f"Unsupported alpha_mode: {alpha_mode}")
 
-    m = precomputed_matrices
     cb = BBCodeCircuit(Hx, Hz, num_cycles=num_cycles, **bb_params)
+    m = precomputed_matrices or build_decoding_matrices(cb, Lx, Lz, error_rate, verbose=False)          # engine.py:207-208
     compiled = CompiledCircuit(base_circuit=cb.get_full_circuit(), noiseless_suffix=cb.cycle * 2, lin_order=cb.lin_order,
                                data_qubits=cb.data_qubits, Xchecks=cb.Xchecks, Zchecks=cb.Zchecks)
     llrs_z, llrs_x = prior_llrs(np.asarray(m["channel_probsZ"], dtype=np.float64)), prior_llrs(np.asarray(m["channel_probsX"], dtype=np.float64))

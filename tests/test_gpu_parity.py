@@ -339,5 +339,31 @@ def test_run_simulation_mirror(L, oracle, golden):
     assert np.array_equal(res["tally"], ref)
     assert res["num_trials"] == 150 and res["logical_errors"] == ref[3] and abs(res["logical_error_rate"] - ref[3] / 150) < 1e-12
     assert set(["logical_error_rate", "z_logical_error_rate", "x_logical_error_rate", "num_trials", "logical_errors"]) <= set(res)
+    # without precomputed matrices the builder runs first and must lead to the identical tally
+    res2 = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=150, num_cycles=6, maxIter=50, base_seed=31337, batch=64, **bb)
+    assert np.array_equal(res2["tally"], ref)
     with pytest.raises(NotImplementedError):
-        run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=10, num_cycles=6, **bb)
+        run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=10, num_cycles=6, osd_order=2, **bb)
+
+
+@pytest.mark.parametrize("tag,code,cycles", [("circ72", "bb72", 6), ("circ144", "bb144", 12)])
+def test_builder_reproduces_reference_matrix_cache(L, tag, code, cycles):
+    """build_decoding_matrices (builder.py:69-176) against the matrices the REFERENCE cached (matrix_cache/*.npz, re-packed as CSR):
+    same columns in the same order, bit-identical summed probabilities, same logical rows."""
+    from qldpc_amd.data import load_code, load_circuit_matrices
+    from qldpc_amd.codes.bb_code import BBCodeCircuit
+    from qldpc_amd.noise.builder import build_decoding_matrices
+    c = load_code(code)
+    d = load_circuit_matrices(tag)
+    cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=cycles, ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"],
+                       b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+    M = build_decoding_matrices(cb, c["Lx"], c["Lz"], 0.005, verbose=False)
+    assert M["k"] == 12 and M["num_cycles"] == cycles
+    for s in "ZX":
+        ip, ix, shape = L.canonical_csr(M[f"Hdec{s}"])
+        assert tuple(shape) == tuple(int(x) for x in d[f"Hdec{s}_shape"])
+        assert np.array_equal(ip, d[f"Hdec{s}_indptr"]) and np.array_equal(ix, d[f"Hdec{s}_indices"])
+        assert np.array_equal(M[f"channel_probs{s}"], d[f"channel_probs{s}"])          # bitwise: same summation order
+        flr = M[f"first_logical_row{s}"]
+        lip, lix, _ = L.canonical_csr(M[f"H{s}_full"][flr:flr + 12])
+        assert np.array_equal(lip, d[f"H{s}_logical_indptr"]) and np.array_equal(lix, d[f"H{s}_logical_indices"])
