@@ -61,6 +61,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     code = load_code(args.code)
+    label = {"bb72": "[[72,12,6]]", "bb144": "[[144,12,12]]", "bb288": "[[288,12,18]]", "bb90": "[[90,8,10]]", "bb108": "[[108,8,10]]",
+             "steane": "[[7,1,3]]"}.get(args.code, args.code)
     m, n, nnz = code["m"], code["n"], int(code["Hx_indptr"][-1])
     graph = _lib.Graph(code["Hx_indptr"], code["Hx_indices"], n, device=local_rank)
     kflag = {"auto": 0, "resident": _lib.FLAG_KERNEL_RESIDENT, "stream": _lib.FLAG_KERNEL_STREAM}[args.kernel]
@@ -134,11 +136,11 @@ def main():
                         "register/LDS resident, so `traffic` (measured HBM bytes) is ~0.04% of it and frac > 1 means HBM is not the bound"}
 
     out = {
-        "metric": "decoded shots/sec, [[144,12,12]] p=0.005 50 BP iters",
+        "metric": f"decoded shots/sec, {label} p={args.p:g} {args.max_iter} BP iters",
         "value": round(value, 1), "unit": "shots/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt_fixed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"[[144,12,12]] Hx {m}x{n} nnz={nnz} code-capacity p={args.p} max_iter={args.max_iter} "
+        "config": {"workload": f"{label} Hx {m}x{n} nnz={nnz} code-capacity p={args.p} max_iter={args.max_iter} "
                                f"dynamic alpha, OSD-0 on BP failures, batch={B} shots/step/GPU, fixed-work mode (all {args.max_iter} "
                                "iterations executed per shot, outputs frozen at convergence)",
                    "code": args.code, "batch": B, "mode": "fixed_iters", "kernel": args.kernel, "seed": SEED},
@@ -151,11 +153,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc          # the checker / CPU baseline, never the product path
         cores = orc.num_threads()
-        probe = 20000
+        probe = 200000        # includes thread start-up; large enough that the rate estimate is meaningful
+        orc.cc_sample_decode_tally(code["Hx_indptr"], code["Hx_indices"], n, code["Lx"], args.p, SEED, 0, 20000, max_iter=args.max_iter, threads=0)
         t0 = time.perf_counter()
         orc.cc_sample_decode_tally(code["Hx_indptr"], code["Hx_indices"], n, code["Lx"], args.p, SEED, 0, probe, max_iter=args.max_iter, threads=0)
         rate = probe / (time.perf_counter() - t0)
-        sample = int(min(K * B, max(probe, rate * args.cpu_seconds)))
+        sample = int(min(max(K * B, 1), max(probe, rate * args.cpu_seconds)))
         t0 = time.perf_counter()
         t_cpu = orc.cc_sample_decode_tally(code["Hx_indptr"], code["Hx_indices"], n, code["Lx"], args.p, SEED, 0, sample,
                                            max_iter=args.max_iter, threads=0)
