@@ -55,10 +55,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     _lib.require_device()                      # fail loudly: no CPU fallback for the product path
+    backend = os.environ.get("QLDPC_BENCH_BACKEND", "nccl")      # "gloo" = rehearsal of the N > 1 path with ranks sharing a GPU
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     code = load_code(args.code)
     label = {"bb72": "[[72,12,6]]", "bb144": "[[144,12,12]]", "bb288": "[[288,12,18]]", "bb90": "[[90,8,10]]", "bb108": "[[108,8,10]]",
@@ -90,13 +97,13 @@ def main():
         for k in range(K):
             plan.run(SEED, shot0(k), B, stream)
         tally = plan.read(stream)             # synchronises the stream
-        tt = torch.from_numpy(tally.copy()).cuda()
+        tt = torch.from_numpy(tally.copy()).to(coll_dev)
         if world > 1:
             dist.all_reduce(tt)               # the one collective of the path (replaces engine.py:450-457)
         barrier()
         dt = time.perf_counter() - t0
         ms_k, launches = plan.kernel_time()
-        td = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        td = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         if world > 1:
             dist.all_reduce(td, op=dist.ReduceOp.MAX)
         plan.close()
