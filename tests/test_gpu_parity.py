@@ -100,6 +100,9 @@ def test_circuit_level_golden(L, golden, oracle, tag):
             sol = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0,
                                       ordering=g[f"{s}_osd_ordering"][t])
             assert np.array_equal(sol, g[f"{s}_osd_solution"][t])
+            sol_w = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=2,
+                                        ordering=g[f"{s}_osd_ordering"][t])       # consistent syndrome: OSD-2 == OSD-0 (osd.py:27-29)
+            assert np.array_equal(sol_w, sol)
             # default (stable) ordering: a valid OSD-0 answer identical to the oracle's with the same rule
             sol2 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0)
             ref2 = oracle.osd0(ip, ix, n, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case])
@@ -342,8 +345,12 @@ def test_run_simulation_mirror(L, oracle, golden):
     # without precomputed matrices the builder runs first and must lead to the identical tally
     res2 = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=150, num_cycles=6, maxIter=50, base_seed=31337, batch=64, **bb)
     assert np.array_equal(res2["tally"], ref)
+    # osd_order=2 (main.py:44): the reference returns the OSD-0 solution whenever it satisfies the syndrome (osd.py:27-29) -> same tally
+    res3 = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=150, num_cycles=6, maxIter=50, osd_order=2,
+                          precomputed_matrices=load_precomputed_matrices("circ72"), base_seed=31337, batch=64, **bb)
+    assert np.array_equal(res3["tally"], ref)
     with pytest.raises(NotImplementedError):
-        run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=10, num_cycles=6, osd_order=2, **bb)
+        run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=10, num_cycles=6, scopt=True, **bb)
 
 
 @pytest.mark.parametrize("tag,code,cycles", [("circ72", "bb72", 6), ("circ144", "bb144", 12)])
