@@ -374,32 +374,40 @@ struct OsdLdsArgs {
     const int8_t *synd; const double *llr; const int8_t *hard; const int32_t *ordering;
     int8_t *solution;
     uint16_t *ordws;               // [grid][n] sorted column order of the shot in flight (global, L2-resident)
-    unsigned long long *dbg;       // optional counters: [0] shots, [1] chunks, [2] columns swept, [3] pivots, [4] cycles, [5] kill passes
-    int offIdx, offAlive, offRows, offPhys, offPos, offPr, offPc, offRc, offB, offNp, offMisc;
+    unsigned long long *dbg;       // optional counters: [0] shots, [1] chunks, [2] columns swept, [3] pivots, [4] cycles, [5] kill passes, [6] blocks
+    int offIdx, offAlive, offRows, offPc, offR, offBlk, offMisc;
 };
+
+constexpr int kOsdBlock = 32;      // columns resolved per block
+__device__ __forceinline__ unsigned long long r_mask_word(const unsigned long long *R, int t, int mw, int w) { return R[t * mw + w]; }
 
 __device__ __forceinline__ unsigned long long osd_key(double x) {
     double a = fabs(x);
     if (a != a) a = INFINITY;
     return (unsigned long long)__double_as_longlong(a);          // non-negative doubles order like their bit patterns
 }
-template <int MW> __device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((MW == 16) ? (w ^ (q & 15)) : w); }
+// U is stored row-major with an XOR swizzle of the word index when rows are 16 words (128 B): conflict-free row-parallel updates
+__device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ (q & 15)) : w); }
 
-template <int MW>
+// Position-space formulation.  T (current rows = T * original rows, rows in their CURRENT physical order, i.e. after the
+// reference's swaps kernels.py:79-82) is kept as U = T^T: U[q] bit p = T[p][q].  Rows 0..m-1 of U belong to the original
+// rows, row m is all zero (padding target of short columns) and row m+1 carries the right-hand side b (it transforms like
+// a column).  The reduced form of a sparse column h is XOR_{i in supp h} U[i]; its pivot is simply the first set bit at a
+// position >= row (kernels.py:71-75); the swap row <-> pivot is a 2-bit swap in every row of U; the elimination
+// (kernels.py:88-92) is U[q] ^= mask for every q whose bit `row` is set.
 __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     extern __shared__ unsigned char lds[];
-    const int m = P.m, n = P.n, mw = (MW > 0) ? MW : P.mw, K = P.K, cd = P.cdeg, tid = threadIdx.x, T = blockDim.x;
+    const int m = P.m, n = P.n, mw = P.mw, K = P.K, cd = P.cdeg, tid = threadIdx.x, T = blockDim.x;
     unsigned long long *U = reinterpret_cast<unsigned long long *>(lds);
     uint16_t *sidx = reinterpret_cast<uint16_t *>(lds + P.offIdx);         // [K] columns of the current chunk
     uint8_t *alive = reinterpret_cast<uint8_t *>(lds + P.offAlive);        // [K]
     uint16_t *colrows = reinterpret_cast<uint16_t *>(lds + P.offRows);     // [K][cd] supports
-    uint16_t *phys = reinterpret_cast<uint16_t *>(lds + P.offPhys), *pos_of = reinterpret_cast<uint16_t *>(lds + P.offPos);
-    uint16_t *pvrow = reinterpret_cast<uint16_t *>(lds + P.offPr), *pvcol = reinterpret_cast<uint16_t *>(lds + P.offPc);
-    unsigned long long *rc = reinterpret_cast<unsigned long long *>(lds + P.offRc);
-    unsigned long long *bvec = reinterpret_cast<unsigned long long *>(lds + P.offB);
-    unsigned long long *npm = reinterpret_cast<unsigned long long *>(lds + P.offNp);   // mask of rows that are not pivots yet
-    unsigned int *misc = reinterpret_cast<unsigned int *>(lds + P.offMisc);
+    uint16_t *pvcol = reinterpret_cast<uint16_t *>(lds + P.offPc);         // [m] pivot t sits at position t
+    unsigned long long *R = reinterpret_cast<unsigned long long *>(lds + P.offR);       // [kOsdBlock][mw] reduced columns -> masks
+    int *blk = reinterpret_cast<int *>(lds + P.offBlk);                    // [0] nb, [1] nops, [2] anydep, [3] next c; [4..] cols[32], opa[32], opp[32], opt[32]
+    int *bcol = blk + 4, *opa = bcol + kOsdBlock, *opp = opa + kOsdBlock, *opt = opp + kOsdBlock;
     uint16_t *ordw = P.ordws + (size_t)blockIdx.x * n;
+    const int brow = m + 1;                                                // U row that carries b
 
     const int total = *P.count;
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
@@ -430,21 +438,18 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
             for (int j = tid; j < n; j += T) ordw[j] = perm[j];
             __syncthreads();
         }
-        // ---- init: T = I, positions = identity, b = s + H hard (osd.py:8-9) ----
-        for (int t = tid; t < (m + 1) * mw; t += T) U[t] = 0ull;          // row m stays zero: padding target of short columns
-        for (int w = tid; w < mw; w += T) { bvec[w] = 0ull; npm[w] = 0ull; }
+        // ---- init: T = I (positions = original rows), b = s + H hard (osd.py:8-9) ----
+        for (int t = tid; t < (m + 2) * mw; t += T) U[t] = 0ull;
         __syncthreads();
         for (int r = tid; r < m; r += T) {
-            U[uswz<MW>(r, r >> 6, mw)] = 1ull << (r & 63);
-            phys[r] = (uint16_t)r; pos_of[r] = (uint16_t)r;
-            atomicOr(&npm[r >> 6], 1ull << (r & 63));
-            int s = synd[r] & 1;
-            for (int e = P.indptr[r]; e < P.indptr[r + 1]; e++) s ^= hard[P.indices[e]] & 1;
-            if (s) atomicOr(&bvec[r >> 6], 1ull << (r & 63));
+            U[uswz(r, r >> 6, mw)] = 1ull << (r & 63);
+            int sy = synd[r] & 1;
+            for (int e = P.indptr[r]; e < P.indptr[r + 1]; e++) sy ^= hard[P.indices[e]] & 1;
+            if (sy) atomicOr(&U[uswz(brow, r >> 6, mw)], 1ull << (r & 63));
         }
         __syncthreads();
-        int row = 0, npiv = 0;
-        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0;
+        int row = 0;
+        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0;
         bool finished = (P.rankH == 0);
         for (int base = 0; base < n && !finished; base += K) {
             const int L = min(K, n - base);
@@ -453,124 +458,134 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 sidx[c] = P.ordering ? (uint16_t)P.ordering[shot * n + base + c] : ordw[base + c];
                 alive[c] = 1;
             }
+            if (tid == 0) blk[3] = 0;
             __syncthreads();
             for (int t = tid; t < L * cd; t += T) {                          // supports of the chunk's columns -> LDS
                 const int c = t / cd, d = t - c * cd, j = sidx[c];
                 const int k = P.colptr[j] + d;
                 colrows[t] = (k < P.colptr[j + 1]) ? (uint16_t)P.rowidx[k] : (uint16_t)m;          // row m of U is all zero
             }
-            if (tid < 3) misc[8 + tid] = 0xFFFFFFFFu;
             __syncthreads();
-            // ================= sweep (kernels.py:64-94 on the reduced sparse columns) =================
-            int step = 0;
-            for (int c = 0; c < L; c++) {
-                if (!alive[c]) continue;                                     // uniform: every thread reads the same byte
-                const bool marked = (alive[c] == 2);
-                const uint16_t *cr = colrows + c * cd;
-                unsigned int *bestp = &misc[8 + step % 3];
-                d_cols++;
-                int ci[8];                                                   // the column's support (<= 8 rows kept in registers)
-#pragma unroll
-                for (int d = 0; d < 8; d++) ci[d] = (d < cd) ? cr[d] : m;
-                if (tid < mw) {                                              // reduced column T h, kept for the elimination
-                    unsigned long long w = 0ull;
-                    if (cd <= 8) {
-#pragma unroll
-                        for (int d = 0; d < 8; d++) w ^= U[uswz<MW>(ci[d], tid, mw)];
-                    } else {
-                        for (int d = 0; d < cd; d++) w ^= U[uswz<MW>(cr[d], tid, mw)];
-                    }
-                    rc[tid] = w;
-                }
-                for (int r = tid; r < m; r += T) {
-                    if (pos_of[r] < row) continue;                           // already a pivot row
-                    unsigned long long w = 0ull;
-                    if (cd <= 8) {
-#pragma unroll
-                        for (int d = 0; d < 8; d++) w ^= U[uswz<MW>(ci[d], r >> 6, mw)];
-                    } else {
-                        for (int d = 0; d < cd; d++) w ^= U[uswz<MW>(cr[d], r >> 6, mw)];
-                    }
-                    if ((w >> (r & 63)) & 1ull) atomicMin(bestp, ((unsigned int)pos_of[r] << 16) | (unsigned int)r);   // kernels.py:71-75
+            // ================= blocks of up to kOsdBlock alive columns =================
+            while (true) {
+                if (tid == 0) {                                              // collect the next alive columns of the chunk
+                    int c = blk[3], nb = 0;
+                    while (c < L && nb < kOsdBlock) { if (alive[c]) bcol[nb++] = c; c++; }
+                    blk[0] = nb; blk[1] = 0; blk[2] = 0; blk[3] = c;
                 }
                 __syncthreads();
-                const unsigned int best = *bestp;
-                if (tid == 0) misc[8 + (step + 2) % 3] = 0xFFFFFFFFu;        // slot used two steps from now
-                step++;
-                if (marked && best != 0xFFFFFFFFu && P.dbg && tid == 0) atomicAdd(&P.dbg[6], 1ull);     // a "dependent" column has a candidate
-                if (best != 0xFFFFFFFFu) {
-                    const int pr = (int)(best & 0xFFFFu), ppos = (int)(best >> 16);
-                    const unsigned long long prbit = 1ull << (pr & 63);
-                    const int prw = pr >> 6;
-                    const bool bpr = (bvec[prw] & prbit) != 0ull;
-                    for (int q = tid; q < m; q += T)                         // rows with a one in this column get the pivot row added
-                        if (U[uswz<MW>(q, prw, mw)] & prbit) {
-                            if (MW > 0) {
-#pragma unroll
-                                for (int w = 0; w < (MW > 0 ? MW : 1); w++) U[uswz<MW>(q, w, mw)] ^= (w == prw) ? (rc[w] & ~prbit) : rc[w];
-                            } else {
-                                for (int w = 0; w < mw; w++) U[uswz<MW>(q, w, mw)] ^= (w == prw) ? (rc[w] & ~prbit) : rc[w];
+                const int nb = blk[0];
+                if (nb == 0) break;
+                d_blocks++; d_cols += nb;
+                // ---- phase 1: reduced columns R[t] = XOR of U rows ----
+                for (int x = tid; x < nb * mw; x += T) {
+                    const int t = x / mw, w = x - t * mw;
+                    const uint16_t *cr = colrows + bcol[t] * cd;
+                    unsigned long long acc = 0ull;
+                    for (int d = 0; d < cd; d++) acc ^= U[uswz(cr[d], w, mw)];
+                    R[t * mw + w] = acc;
+                }
+                __syncthreads();
+                // ---- phase 2: one wave resolves the pivots of the block on the local matrix ----
+                if (tid < 64) {
+                    const int lane = tid, w = lane & 15, grp = lane >> 4;
+                    int lrow = row, nops = 0, anydep = 0;
+                    for (int t = 0; t < nb; t++) {
+                        unsigned long long r = (w < mw) ? R[t * mw + w] : 0ull;
+                        const int wq = lrow >> 6;
+                        unsigned long long mword = (w < wq) ? 0ull : ((w == wq) ? (r & (~0ull << (lrow & 63))) : r);
+                        const unsigned long long bal = __ballot(mword != 0ull && grp == 0) & 0xFFFFull;
+                        if (bal == 0ull) { anydep = 1; if (lane == 0) alive[bcol[t]] = 0; continue; }          // dependent on the pivots so far
+                        const int pw = __builtin_ctzll(bal);
+                        const unsigned long long pword = __shfl(mword, pw);
+                        const int pp = pw * 64 + __builtin_ctzll(pword);                               // first candidate position (kernels.py:71-75)
+                        const int a = lrow, wa = a >> 6, wp = pp >> 6;
+                        const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
+                        // swap bits a <-> pp of the pivot column itself (bit pp is 1), then clear bit a: that is the elimination mask
+                        const unsigned long long ra = __shfl(r, wa);
+                        const bool olda = (ra & abit) != 0ull;
+                        if (w == wp) r = olda ? (r | pbit) : (r & ~pbit);
+                        if (w == wa) r &= ~abit;
+                        if (grp == 0 && w < mw) R[t * mw + w] = r;                                     // R[t] now holds mask_t
+                        asm volatile("" ::: "memory");
+                        // later columns of the block: same swap, then add the mask where the pivot bit is set (kernels.py:88-92)
+                        for (int s0 = t + 1; s0 < nb; s0 += 4) {
+                            const int s = s0 + grp;
+                            if (s < nb && w < mw) {
+                                unsigned long long x = R[s * mw + w];
+                                const unsigned long long xa = R[s * mw + wa], xp = R[s * mw + wp];
+                                const bool ba = (xa & abit) != 0ull, bp = (xp & pbit) != 0ull;
+                                if (ba != bp) { if (w == wa) x ^= abit; if (w == wp) x ^= pbit; }
+                                if (bp) x ^= r_mask_word(R, t, mw, w);                                 // after the swap, bit a of column s is bp
+                                R[s * mw + w] = x;
                             }
+                            asm volatile("" ::: "memory");
                         }
-                    if (tid < mw && bpr) bvec[tid] ^= (tid == prw) ? (rc[tid] & ~prbit) : rc[tid];     // bit pr itself never changes
-                    if (tid == 0) {                                          // the reference's row swap (kernels.py:79-82) as positions
-                        const int r0 = phys[row];
-                        phys[row] = (uint16_t)pr; phys[ppos] = (uint16_t)r0; pos_of[pr] = (uint16_t)row; pos_of[r0] = (uint16_t)ppos;
-                    } else if (tid == 64) {
-                        pvrow[npiv] = (uint16_t)pr; pvcol[npiv] = sidx[c];
-                        npm[prw] &= ~prbit;
+                        if (lane == 0) { opa[nops] = a; opp[nops] = pp; opt[nops] = t; pvcol[a] = sidx[bcol[t]]; }
+                        nops++; lrow++;
+                        if (lrow >= P.rankH || lrow >= m) {                                             // full rank: the remaining columns cannot pivot
+                            break;
+                        }
                     }
-                    row++; npiv++;
-                    __syncthreads();
-                    if (row >= P.rankH || row >= m) { finished = true; break; }
-                } else {
-                    // column c depends on the pivots so far.  So may many of the columns behind it: test them all at once.
+                    if (lane == 0) { blk[1] = nops; blk[2] = anydep; }
+                }
+                __syncthreads();
+                const int nops = blk[1], anydep = blk[2];
+                // ---- phase 3: apply the block's operations to every row of U (and to b) ----
+                for (int q = tid; q < m + 2; q += T) {
+                    if (q == m) continue;
+                    for (int k = 0; k < nops; k++) {
+                        const int a = opa[k], pp = opp[k], wa = a >> 6, wp = pp >> 6;
+                        const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
+                        unsigned long long xa = U[uswz(q, wa, mw)];
+                        const unsigned long long xp = (wp == wa) ? xa : U[uswz(q, wp, mw)];
+                        const bool ba = (xa & abit) != 0ull, bp = (xp & pbit) != 0ull;
+                        if (ba != bp) {
+                            if (wp == wa) { U[uswz(q, wa, mw)] = xa ^ abit ^ pbit; }
+                            else { U[uswz(q, wa, mw)] = xa ^ abit; U[uswz(q, wp, mw)] = xp ^ pbit; }
+                        }
+                        if (bp) {                                            // bit a after the swap
+                            const unsigned long long *mk = R + opt[k] * mw;
+                            for (int w = 0; w < mw; w++) U[uswz(q, w, mw)] ^= mk[w];
+                        }
+                    }
+                }
+                row += nops;
+                __syncthreads();
+                if (row >= P.rankH || row >= m) { finished = true; break; }
+                // ---- dependent columns were met: drop every column of the chunk that is dependent by now ----
+                if (anydep && !P.nokill) {
                     d_kills++;
-                    for (int c2 = c + 1 + tid; c2 < L && P.nokill != 1; c2 += T) {
+                    const int c0 = blk[3];
+                    const int wq = row >> 6;
+                    for (int c2 = c0 + tid; c2 < L; c2 += T) {
                         if (!alive[c2]) continue;
                         const uint16_t *cr2 = colrows + c2 * cd;
                         unsigned long long any = 0ull;
-                        if (cd <= 8) {
-                            int c2i[8];
-#pragma unroll
-                            for (int d = 0; d < 8; d++) c2i[d] = (d < cd) ? cr2[d] : m;
-                            for (int w = 0; w < mw; w++) {
-                                unsigned long long x = 0ull;
-#pragma unroll
-                                for (int d = 0; d < 8; d++) x ^= U[uswz<MW>(c2i[d], w, mw)];
-                                any |= x & npm[w];
-                            }
-                        } else {
-                            for (int w = 0; w < mw; w++) {
-                                unsigned long long x = 0ull;
-                                for (int d = 0; d < cd; d++) x ^= U[uswz<MW>(cr2[d], w, mw)];
-                                any |= x & npm[w];
-                            }
+                        for (int w = wq; w < mw; w++) {
+                            unsigned long long x = 0ull;
+                            for (int d = 0; d < cd; d++) x ^= U[uswz(cr2[d], w, mw)];
+                            any |= (w == wq) ? (x & (~0ull << (row & 63))) : x;
                         }
-                        if (!any) alive[c2] = (P.nokill == 2) ? 2 : 0;
-                    }
-                    if (P.nokill == 2 && P.dbg) {       // cross-check the non-pivot mask against the position table
-                        for (int r = tid; r < m; r += T) {
-                            const bool np1 = (npm[r >> 6] >> (r & 63)) & 1ull, np2 = pos_of[r] >= row;
-                            if (np1 != np2) atomicAdd(&P.dbg[7], 1ull);
-                        }
+                        if (!any) alive[c2] = 0;
                     }
                     __syncthreads();
                 }
             }
-            __syncthreads();      // the tail of a chunk may be all skipped columns: nobody may refill alive[]/sidx[] while others still scan it
+            __syncthreads();      // nobody may refill alive[]/sidx[] while others still use them
         }
         if (P.dbg && tid == 0) {
-            atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)npiv);
-            atomicAdd(&P.dbg[4], (unsigned long long)(clock64() - t_start)); atomicAdd(&P.dbg[5], d_kills);
+            atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)row);
+            atomicAdd(&P.dbg[4], (unsigned long long)(clock64() - t_start)); atomicAdd(&P.dbg[5], d_kills); atomicAdd(&P.dbg[6], d_blocks);
         }
         // ---- back-fill (osd.py:19-25): e[pivot col] = reduced rhs at the pivot row; solution = (hard + e) % 2 ----
         __syncthreads();
         if (sol != hard) for (int j = tid; j < n; j += T) sol[j] = hard[j];
         __syncthreads();
-        for (int t = tid; t < npiv; t += T) {
-            const int j = pvcol[t], r = pvrow[t];
-            sol[j] = (int8_t)((hard[j] ^ (int8_t)((bvec[r >> 6] >> (r & 63)) & 1ull)) & 1);
+        for (int t = tid; t < row; t += T) {
+            const int j = pvcol[t];
+            const int8_t bbit = (int8_t)((U[uswz(brow, t >> 6, mw)] >> (t & 63)) & 1ull);
+            sol[j] = (int8_t)((hard[j] ^ bbit) & 1);
         }
         __syncthreads();
     }
@@ -602,18 +617,14 @@ static bool plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
     P.m = g->m; P.n = g->n; P.mw = (g->m + 63) / 64; P.K = 1024; P.cdeg = std::max(g->max_col_deg, 1);
     P.npad = 1;
     while (P.npad < g->n) P.npad <<= 1;
-    size_t off = std::max((size_t)(g->m + 1) * P.mw * 8, (size_t)g->n * 8 + (size_t)P.npad * 2);     // U, aliased by the sort scratch
+    size_t off = std::max((size_t)(g->m + 2) * P.mw * 8, (size_t)g->n * 8 + (size_t)P.npad * 2);     // U, aliased by the sort scratch
     off = (size_t)round_up((int64_t)off, 16);
     P.offIdx = (int)off; off += (size_t)P.K * 2;
     P.offAlive = (int)off; off += (size_t)P.K;
     P.offRows = (int)off; off += (size_t)P.K * P.cdeg * 2;
-    P.offPhys = (int)off; off += round_up((int64_t)g->m * 2, 8);
-    P.offPos = (int)off; off += round_up((int64_t)g->m * 2, 8);
-    P.offPr = (int)off; off += round_up((int64_t)g->m * 2, 8);
     P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
-    P.offRc = (int)off; off += (size_t)P.mw * 8;
-    P.offB = (int)off; off += (size_t)P.mw * 8;
-    P.offNp = (int)off; off += (size_t)P.mw * 8;
+    P.offR = (int)off; off += (size_t)kOsdBlock * P.mw * 8;
+    P.offBlk = (int)off; off += (4 + 4 * kOsdBlock) * 4;
     P.offMisc = (int)off; off += 64;
     lds = off + 16;
     return lds <= 160 * 1024;
@@ -640,22 +651,16 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
         else {
             unsigned long long h[8];
             QLDPC_HIP_TRY(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));      // counters of the previous launches
-            if (h[0]) fprintf(stderr, "[osd dbg] shots=%llu chunks/shot=%.2f cols/shot=%.1f pivots/shot=%.1f kills/shot=%.1f kcycles/shot=%.1f rankH=%d viol=%llu maskdiff=%llu\n",
-                              h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[5] / h[0], (double)h[4] / h[0] / 1e3, g->gf2_rank, h[6], h[7]);
+            if (h[0]) fprintf(stderr, "[osd dbg] shots=%llu chunks/shot=%.2f cols/shot=%.1f pivots/shot=%.1f kills/shot=%.1f blocks/shot=%.1f kcycles/shot=%.1f rankH=%d\n",
+                              h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[4] / h[0] / 1e3, g->gf2_rank);
         }
         P.dbg = d_dbg;
     }
-    const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m, 256), 64));
-    P.nokill = getenv("QLDPC_OSD_NOKILL") ? atoi(getenv("QLDPC_OSD_NOKILL")) : 0;
-    if (P.mw == 16 && !getenv("QLDPC_OSD_GENERIC")) {
-        static bool a16 = false;
-        if (!a16) { QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a16 = true; }
-        hipLaunchKernelGGL(osd0_lds_kernel<16>, dim3(grid), dim3(block), lds, stream, P);
-    } else {
-        static bool a0 = false;
-        if (!a0) { QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a0 = true; }
-        hipLaunchKernelGGL(osd0_lds_kernel<0>, dim3(grid), dim3(block), lds, stream, P);
-    }
+    P.nokill = getenv("QLDPC_OSD_NOKILL") ? 1 : 0;
+    const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m + 2, 256), 64));
+    static bool attr = false;
+    if (!attr) { QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(osd0_lds_kernel, dim3(grid), dim3(block), lds, stream, P);
     QLDPC_HIP_TRY(hipGetLastError());
     handled = true;
     return QLDPC_OK;
