@@ -378,7 +378,11 @@ struct OsdLdsArgs {
     int offIdx, offAlive, offRows, offPc, offR, offBlk, offMisc;
 };
 
-constexpr int kOsdBlock = 32;      // columns resolved per block
+#ifndef QLDPC_OSD_BLOCK
+#define QLDPC_OSD_BLOCK 16
+#endif
+constexpr int kOsdBlock = QLDPC_OSD_BLOCK;      // columns resolved per block (4 per register of the resolving wave)
+constexpr int kOsdRegs = kOsdBlock / 4;
 __device__ __forceinline__ unsigned long long r_mask_word(const unsigned long long *R, int t, int mw, int w) { return R[t * mw + w]; }
 
 __device__ __forceinline__ unsigned long long osd_key(double x) {
@@ -449,7 +453,8 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         }
         __syncthreads();
         int row = 0;
-        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0;
+        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0;
+        const long long t_sorted = clock64();
         bool finished = (P.rankH == 0);
         for (int base = 0; base < n && !finished; base += K) {
             const int L = min(K, n - base);
@@ -468,15 +473,31 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
             __syncthreads();
             // ================= blocks of up to kOsdBlock alive columns =================
             while (true) {
-                if (tid == 0) {                                              // collect the next alive columns of the chunk
-                    int c = blk[3], nb = 0;
-                    while (c < L && nb < kOsdBlock) { if (alive[c]) bcol[nb++] = c; c++; }
-                    blk[0] = nb; blk[1] = 0; blk[2] = 0; blk[3] = c;
+                if (tid < 64) {                                              // wave 0 collects the next alive columns of the chunk (ballot scan)
+                    int c = blk[3], nbc = 0;
+                    while (c < L && nbc < kOsdBlock) {
+                        const int cc = c + tid;
+                        const bool al = (cc < L) && alive[cc];
+                        const unsigned long long bal = __ballot(al);
+                        const int before = __builtin_popcountll(bal & ((1ull << tid) - 1ull));
+                        if (al && nbc + before < kOsdBlock) bcol[nbc + before] = cc;
+                        const int got = __builtin_popcountll(bal);
+                        if (nbc + got >= kOsdBlock) {                         // stop right behind the column that filled the block
+                            int need = kOsdBlock - nbc;
+                            unsigned long long bb = bal;
+                            int lastpos = 0;
+                            while (need-- > 0) { lastpos = __builtin_ctzll(bb); bb &= bb - 1; }
+                            c += lastpos + 1; nbc = kOsdBlock;
+                        } else { nbc += got; c += 64; }
+                    }
+                    if (c > L) c = L;
+                    if (tid == 0) { blk[0] = nbc; blk[1] = 0; blk[2] = 0; blk[3] = c; }
                 }
                 __syncthreads();
                 const int nb = blk[0];
                 if (nb == 0) break;
                 d_blocks++; d_cols += nb;
+                long long tp = clock64();
                 // ---- phase 1: reduced columns R[t] = XOR of U rows ----
                 for (int x = tid; x < nb * mw; x += T) {
                     const int t = x / mw, w = x - t * mw;
@@ -486,50 +507,60 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     R[t * mw + w] = acc;
                 }
                 __syncthreads();
+                c_p1 += clock64() - tp; tp = clock64();
                 // ---- phase 2: one wave resolves the pivots of the block on the local matrix ----
                 if (tid < 64) {
+                    // local matrix in registers: lane = (grp, w); register j holds word w of column 4*j + grp
                     const int lane = tid, w = lane & 15, grp = lane >> 4;
+                    unsigned long long X[kOsdRegs];
+#pragma unroll
+                    for (int j = 0; j < kOsdRegs; j++) { const int sc = 4 * j + grp; X[j] = (sc < nb && w < mw) ? R[sc * mw + w] : 0ull; }
                     int lrow = row, nops = 0, anydep = 0;
                     for (int t = 0; t < nb; t++) {
-                        unsigned long long r = (w < mw) ? R[t * mw + w] : 0ull;
+                        const int jt = t >> 2, gt = t & 3;
+                        unsigned long long mine = 0ull;
+#pragma unroll
+                        for (int j = 0; j < kOsdRegs; j++) if (j == jt) mine = X[j];                  // uniform select of register jt
+                        const unsigned long long rp = __shfl(mine, gt * 16 + w);                      // word w of the pivot column, in every group
                         const int wq = lrow >> 6;
-                        unsigned long long mword = (w < wq) ? 0ull : ((w == wq) ? (r & (~0ull << (lrow & 63))) : r);
+                        const unsigned long long mword = (w < wq) ? 0ull : ((w == wq) ? (rp & (~0ull << (lrow & 63))) : rp);
                         const unsigned long long bal = __ballot(mword != 0ull && grp == 0) & 0xFFFFull;
-                        if (bal == 0ull) { anydep = 1; if (lane == 0) alive[bcol[t]] = 0; continue; }          // dependent on the pivots so far
+                        if (bal == 0ull) { anydep = 1; if (lane == 0) alive[bcol[t]] = 0; continue; }  // dependent on the pivots so far
                         const int pw = __builtin_ctzll(bal);
                         const unsigned long long pword = __shfl(mword, pw);
                         const int pp = pw * 64 + __builtin_ctzll(pword);                               // first candidate position (kernels.py:71-75)
                         const int a = lrow, wa = a >> 6, wp = pp >> 6;
                         const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
                         // swap bits a <-> pp of the pivot column itself (bit pp is 1), then clear bit a: that is the elimination mask
-                        const unsigned long long ra = __shfl(r, wa);
-                        const bool olda = (ra & abit) != 0ull;
-                        if (w == wp) r = olda ? (r | pbit) : (r & ~pbit);
-                        if (w == wa) r &= ~abit;
-                        if (grp == 0 && w < mw) R[t * mw + w] = r;                                     // R[t] now holds mask_t
-                        asm volatile("" ::: "memory");
+                        const bool la = (w == wa), lp = (w == wp);
+                        const bool olda = __ballot(grp == 0 && la && (rp & abit) != 0ull) != 0ull;
+                        unsigned long long rm = rp;
+                        if (w == wp) rm = olda ? (rm | pbit) : (rm & ~pbit);
+                        if (w == wa) rm &= ~abit;
                         // later columns of the block: same swap, then add the mask where the pivot bit is set (kernels.py:88-92)
-                        for (int s0 = t + 1; s0 < nb; s0 += 4) {
-                            const int s = s0 + grp;
-                            if (s < nb && w < mw) {
-                                unsigned long long x = R[s * mw + w];
-                                const unsigned long long xa = R[s * mw + wa], xp = R[s * mw + wp];
-                                const bool ba = (xa & abit) != 0ull, bp = (xp & pbit) != 0ull;
-                                if (ba != bp) { if (w == wa) x ^= abit; if (w == wp) x ^= pbit; }
-                                if (bp) x ^= r_mask_word(R, t, mw, w);                                 // after the swap, bit a of column s is bp
-                                R[s * mw + w] = x;
-                            }
-                            asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < kOsdRegs; j++) {
+                            if (4 * j + 3 < t) continue;                                              // (uniform) all four columns of this register are done
+                            const int sc = 4 * j + grp;
+                            unsigned long long x = X[j];
+                            // bits a / pp of the column live in the lanes holding words wa / wp of this group: two ballots instead of shuffles
+                            const unsigned long long balA = __ballot(la && (x & abit) != 0ull), balP = __ballot(lp && (x & pbit) != 0ull);
+                            const bool ba = (balA >> (grp * 16 + wa)) & 1ull, bp = (balP >> (grp * 16 + wp)) & 1ull;
+                            if (ba != bp) { if (la) x ^= abit; if (lp) x ^= pbit; }
+                            if (bp) x ^= rm;                                                          // after the swap, bit a of the column is bp
+                            if (sc == t) x = rm;                                                      // the pivot column's slot keeps the mask
+                            if (sc >= t && sc < nb) X[j] = x;
                         }
                         if (lane == 0) { opa[nops] = a; opp[nops] = pp; opt[nops] = t; pvcol[a] = sidx[bcol[t]]; }
                         nops++; lrow++;
-                        if (lrow >= P.rankH || lrow >= m) {                                             // full rank: the remaining columns cannot pivot
-                            break;
-                        }
+                        if (lrow >= P.rankH || lrow >= m) break;                                       // full rank: the remaining columns cannot pivot
                     }
+#pragma unroll
+                    for (int j = 0; j < kOsdRegs; j++) { const int sc = 4 * j + grp; if (sc < nb && w < mw) R[sc * mw + w] = X[j]; }
                     if (lane == 0) { blk[1] = nops; blk[2] = anydep; }
                 }
                 __syncthreads();
+                c_p2 += clock64() - tp; tp = clock64();
                 const int nops = blk[1], anydep = blk[2];
                 // ---- phase 3: apply the block's operations to every row of U (and to b) ----
                 for (int q = tid; q < m + 2; q += T) {
@@ -552,6 +583,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 }
                 row += nops;
                 __syncthreads();
+                c_p3 += clock64() - tp; tp = clock64();
                 if (row >= P.rankH || row >= m) { finished = true; break; }
                 // ---- dependent columns were met: drop every column of the chunk that is dependent by now ----
                 if (anydep && !P.nokill) {
@@ -570,6 +602,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                         if (!any) alive[c2] = 0;
                     }
                     __syncthreads();
+                    c_kill += clock64() - tp;
                 }
             }
             __syncthreads();      // nobody may refill alive[]/sidx[] while others still use them
@@ -577,6 +610,8 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         if (P.dbg && tid == 0) {
             atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)row);
             atomicAdd(&P.dbg[4], (unsigned long long)(clock64() - t_start)); atomicAdd(&P.dbg[5], d_kills); atomicAdd(&P.dbg[6], d_blocks);
+            atomicAdd(&P.dbg[8], (unsigned long long)(t_sorted - t_start)); atomicAdd(&P.dbg[9], c_p1); atomicAdd(&P.dbg[10], c_p2); atomicAdd(&P.dbg[11], c_p3);
+            atomicAdd(&P.dbg[12], c_kill);
         }
         // ---- back-fill (osd.py:19-25): e[pivot col] = reduced rhs at the pivot row; solution = (hard + e) % 2 ----
         __syncthreads();
@@ -647,12 +682,13 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     static unsigned long long *d_dbg = nullptr;
     P.dbg = nullptr;
     if (getenv("QLDPC_OSD_DEBUG")) {
-        if (!d_dbg) { QLDPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_dbg), 64)); QLDPC_HIP_TRY(hipMemset(d_dbg, 0, 64)); }
+        if (!d_dbg) { QLDPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_dbg), 128)); QLDPC_HIP_TRY(hipMemset(d_dbg, 0, 128)); }
         else {
-            unsigned long long h[8];
+            unsigned long long h[16];
             QLDPC_HIP_TRY(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));      // counters of the previous launches
-            if (h[0]) fprintf(stderr, "[osd dbg] shots=%llu chunks/shot=%.2f cols/shot=%.1f pivots/shot=%.1f kills/shot=%.1f blocks/shot=%.1f kcycles/shot=%.1f rankH=%d\n",
-                              h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[4] / h[0] / 1e3, g->gf2_rank);
+            if (h[0]) fprintf(stderr, "[osd dbg] shots=%llu chunks/shot=%.2f cols/shot=%.1f pivots/shot=%.1f kills/shot=%.1f blocks/shot=%.1f kcycles/shot=%.1f (sort %.0f p1 %.0f p2 %.0f p3 %.0f kill %.0f) rankH=%d\n",
+                              h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[4] / h[0] / 1e3,
+                              (double)h[8] / h[0] / 1e3, (double)h[9] / h[0] / 1e3, (double)h[10] / h[0] / 1e3, (double)h[11] / h[0] / 1e3, (double)h[12] / h[0] / 1e3, g->gf2_rank);
         }
         P.dbg = d_dbg;
     }
