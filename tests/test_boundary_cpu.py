@@ -103,3 +103,21 @@ def test_canonical_csr_and_data(L):
     assert np.array_equal(ip2, ip) and np.array_equal(ix2, ix)
     d = load_circuit_matrices("circ144")
     assert tuple(d["HdecZ_shape"]) == (1008, 8785) and d["HdecZ_indptr"][-1] == 30672
+
+
+def test_cache_key_and_format(tmp_path):
+    """the key recipe must reproduce the names of the reference's own cache files (matrix_cache/matrices_<key>.npz)."""
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd.data import load_code
+    from qldpc_amd.utils.caching import compute_cache_key, save_matrices, load_matrices
+    for tag, cycles, want in (("bb144", 12, "d63ef327adf94be6"), ("bb72", 6, "61d7ee9cf7e4c9ee")):
+        c = load_code(tag)
+        key = compute_cache_key(c["Hx"].astype(np.int64), c["Hz"].astype(np.int64), c["Lx"].astype(np.uint8), c["Lz"].astype(np.uint8), cycles, 0.005)
+        assert key == want
+    M = {"HdecZ": np.eye(3, 5, dtype=int), "HdecX": np.eye(3, 4, dtype=int), "channel_probsZ": np.arange(5) / 10, "channel_probsX": np.arange(4) / 7,
+         "HZ_full": np.ones((4, 5), int), "HX_full": np.ones((4, 4), int), "first_logical_rowZ": 3, "first_logical_rowX": 3, "num_cycles": 2, "k": 1}
+    path = save_matrices(str(tmp_path), "abc", M)
+    assert os.path.basename(path) == "matrices_abc.npz"
+    back = load_matrices(str(tmp_path), "abc")
+    assert all(np.array_equal(back[k], M[k]) for k in M)
+    assert load_matrices(str(tmp_path), "missing") is None
