@@ -7,9 +7,9 @@
 // columns), but with compile-time degrees the check update is straight-line code:
 //   * Q = clip(V[col] - R) as v_min_f64/v_max_f64 (the NaN test of kernels.py:328 is kept unless the launcher proved
 //     that no NaN can arise: finite prior/clip/alpha and every check degree >= 2);
-//   * min1 = min-tree, argmin = FIRST lane of the equality mask (the reference's strict '<' keeps the first minimum,
-//     kernels.py:301-304), min2 = min-tree with that entry masked to +inf (duplicates of min1 therefore count,
-//     kernels.py:305-306);
+//   * min1 / min2 = the two smallest magnitudes WITH multiplicity, from a 14-op v_min/v_max network (kernels.py:301-306);
+//     the position that receives min2 is selected by |q| == min1: if the minimum is attained twice, min2 == min1, so
+//     this equals the reference's "first strict minimum" rule at every position;
 //   * signs are boolean masks (x < 0; note -0.0 counts as >= 0 exactly like `val >= 0`, kernels.py:296), the message is
 //     (+-alpha) * mag, one rounding, equal to the reference's (alpha * sign) * mag.
 // MC = true fuses the sampler (Philox4x32-10 stream of mc_common.h), the GF(2) syndrome (a6), the decode, the logical
@@ -38,7 +38,6 @@ struct RegArgs {
     const struct RegCold *cold;     // rarely used pointers live in device memory to keep scalar registers free
     // LDS carve (byte offsets)
     int offV, offE, offL, offI, offA, offT;
-    int exp;                        // QLDPC_EXP timing experiments (0 in production)
 };
 
 struct RegCold {
@@ -220,11 +219,11 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
                         const int hi = (eq ? p2hi : p1hi) ^ ((sp != neg[k]) ? (int)0x80000000 : 0);   // kernels.py:311-314
                         const double msg = __hiloint2double(hi, lo);
                         Rprev[k] = msg;
-                        if (!(A.exp & 2)) Rl[roff + k] = msg;
+                        Rl[roff + k] = msg;
                     }
                 }
             }
-            if (!(A.exp & 1)) __syncthreads();
+            __syncthreads();
             // ======== variable phase: freeze test, then values_it ========
             if (valid && !done) {
                 const bool conv = (it >= 1) && (unsat[it & 1] == 0);                           // kernels.py:361-364
@@ -268,10 +267,10 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
 #pragma unroll
                         for (int d = 0; d < VDEG; d++) s += Rl[voff[v][d]];                    // kernels.py:316, ascending check order
                         const double xv = s + vprior[v];                                       // kernels.py:320
-                        if (!(A.exp & 2)) Vl[vj[v]] = xv;
+                        Vl[vj[v]] = xv;
                     }
             }
-            if (!(A.exp & 1)) __syncthreads();
+            __syncthreads();
             if (!A.fixed && active[0] == 0) break;
         }
         __syncthreads();
@@ -418,7 +417,6 @@ static void fill_common(const qldpc_graph *g, const RegPlan &P, RegArgs &A, int6
     A.S = P.S; A.TS = P.TS;
     A.indptr = g->d_indptr; A.indices = g->d_indices; A.colptr = g->d_colptr; A.rowidx = g->d_rowidx; A.csc2csr = g->d_csc2csr;
     A.B = B; A.prior = d_prior; A.alpha = d_alpha; A.damping = damping; A.clip = clip;
-    if (const char *e = getenv("QLDPC_EXP")) A.exp = atoi(e);
     A.offV = P.offV; A.offE = P.offE; A.offL = P.offL; A.offI = P.offI; A.offA = P.offA; A.offT = P.offT;
 }
 

@@ -16,6 +16,9 @@ LLR_TOL = 1e-5
 def L():
     import qldpc_amd  # noqa: F401
     from qldpc_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):          # a fresh checkout: build the HIP library first (never fall back to anything else)
+        import __graft_entry__
+        __graft_entry__.build()
     _lib.require_device()
     return _lib
 

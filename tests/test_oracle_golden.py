@@ -178,3 +178,24 @@ def test_circuit_level_decode_and_osd(oracle, golden, tag):
     if tag == "circ144":
         assert (data["channel_probsZ"] > 1).sum() == 1 and (g["llrs_Z"] == 0).sum() >= 1   # log(negative) -> NaN -> 0
     assert np.isinf(g["X_llr"]).any()           # degree-1 checks -> +-inf posteriors (SURVEY hard parts)
+
+
+def test_philox_circuit_trial_equals_explicit_random_path(oracle, golden):
+    """The oracle's Philox-driven trial (the checker of the GPU sampler) == the golden-pinned explicit-random composition
+    when the random arrays are derived from the same Philox words."""
+    g = golden("circ72_noise")
+    circ = oracle.make_circuit(g, g["Lx"], g["Lz"])
+    n_locs = int(g["num_error_locs"])
+    for p, seed, trial in ((0.005, 7, 3), (0.05, 11, 123456789012)):
+        thr = oracle.bernoulli_threshold(p)
+        rv, rp, rt = np.ones(n_locs), np.zeros(n_locs, np.int32), np.zeros(n_locs, np.int32)
+        for l in range(n_locs):
+            o = oracle.philox([trial & 0xFFFFFFFF, trial >> 32, l >> 2, 1], [seed, 0])
+            if o[l & 3] < thr:
+                w = oracle.philox([trial & 0xFFFFFFFF, trial >> 32, l, 2], [seed, 0])
+                rv[l], rp[l], rt[l] = 0.0, w[0] % 3, w[0] % 15
+        want = oracle.run_trial(g, p, rv, rp, rt)
+        got = oracle.circuit_sample(circ, p, seed, trial)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        assert (rv == 0).sum() > 0
