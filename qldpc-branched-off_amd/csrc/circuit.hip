@@ -358,7 +358,9 @@ QLDPC_EXPORT int qldpc_circuit_plan_create(const qldpc_circuit_desc *D, const ql
     std::vector<double> az, ax;
     if ((rc = build_alpha_table(max_iter, alpha_mode, alpha_val_z, alpha_seq_z, alpha_len_z, az)) != QLDPC_OK) return fail(rc);
     if ((rc = build_alpha_table(max_iter, alpha_mode, alpha_val_x, alpha_seq_x, alpha_len_x, ax)) != QLDPC_OK) return fail(rc);
-    P->nanfree = false;      // circuit-level graphs have degree-1 checks (+-inf messages): keep the NaN test (SURVEY hard parts)
+    // "clean" inputs (finite, no -0.0 priors, positive finite clip / alphas) select the lean kernel; graphs with degree-1 checks
+    // (+-inf messages) still keep the NaN test of kernels.py:328 inside it
+    P->nanfree = inputs_clean(prior_z, gz->n, clip_llr, az.data(), max_iter) && inputs_clean(prior_x, gx->n, clip_llr, ax.data(), max_iter);
     std::vector<int32_t> zp, xp;
     std::vector<uint16_t> zi, xi;
     std::vector<uint64_t> zl, xl;

@@ -24,6 +24,13 @@ int build_alpha_table(int max_iter, int alpha_mode, double alpha_val, const doub
 
 bool resident_supported(const qldpc_graph *g, double damping);
 
+bool inputs_clean(const double *prior, int n, double clip, const double *alpha, int n_alpha) {
+    if (!(std::isfinite(clip) && clip > 0.0)) return false;
+    for (int k = 0; k < n_alpha; k++) if (!(std::isfinite(alpha[k]) && alpha[k] > 0.0)) return false;
+    for (int j = 0; j < n; j++) if (!std::isfinite(prior[j]) || (prior[j] == 0.0 && std::signbit(prior[j]))) return false;
+    return true;
+}
+
 int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
                            const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
                            uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
@@ -40,7 +47,7 @@ int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     if (!want_stream && can_res)
         return minsum_resident_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
     if (!want_stream && wg_supported(g, damping))
-        return minsum_wg_launch(g, B, d_synd, d_prior, max_iter, d_alpha, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
+        return minsum_wg_launch(g, B, d_synd, d_prior, max_iter, d_alpha, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
     return minsum_stream_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
 }
 
@@ -77,8 +84,8 @@ static int decode_dev_impl(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     if ((rc = g->ws_alpha.ensure(tab.size() * sizeof(double))) != QLDPC_OK) return rc;
     QLDPC_HIP_TRY(hipMemcpyAsync(g->ws_alpha.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
     QLDPC_HIP_TRY(hipStreamSynchronize(s));   // tab is a stack temporary: the copy must have left host memory
-    bool nanfree = prior_finite && std::isfinite(clip_llr) && std::isfinite(damping);
-    for (double a : tab) nanfree = nanfree && std::isfinite(a);
+    // prior_finite here means "host-verified clean prior" (finite, no -0.0); clip and alphas are checked the same way
+    bool nanfree = prior_finite && std::isfinite(damping) && inputs_clean(nullptr, 0, clip_llr, tab.data(), max_iter);
     return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, g->ws_alpha.as<double>(), damping, clip_llr, flags, nanfree, d_err,
                                   d_llr, d_conv, d_iter, s);
 }
@@ -107,8 +114,8 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, cons
         return rc;
     if (m) QLDPC_HIP_TRY(hipMemcpy(d_synd.p, syndromes, B * m, hipMemcpyHostToDevice));
     if (n) QLDPC_HIP_TRY(hipMemcpy(d_prior.p, prior, n * 8, hipMemcpyHostToDevice));
-    bool prior_finite = true;
-    for (size_t j = 0; j < n; j++) prior_finite = prior_finite && std::isfinite(prior[j]);
+    const double one = 1.0;
+    const bool prior_finite = inputs_clean(prior, (int)n, 1.0, &one, 1);
     rc = decode_dev_impl(g, B, d_synd.as<int8_t>(), d_prior.as<double>(), max_iter, alpha_mode, alpha_val, alpha_seq,
                          alpha_len, damping, clip_llr, flags, prior_finite, d_err.as<int8_t>(), d_llr.as<double>(),
                          d_conv.as<uint8_t>(), d_iter.as<int32_t>(), nullptr);

@@ -162,8 +162,10 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
         for (size_t j = 0; j < n; j++)
             if (L[(size_t)r * n + j] & 1) Lmask[j] |= (uint64_t)1 << r;
     auto fail = [&](int code) { qldpc_cc_plan_destroy(P); return code; };
-    P->nanfree = std::isfinite(clip_llr);
-    for (double a : P->alpha) P->nanfree = P->nanfree && std::isfinite(a);
+    {
+        const double pr = std::log((1.0 - p) / p);
+        P->nanfree = inputs_clean(&pr, 1, clip_llr, P->alpha.data(), max_iter);
+    }
     P->fused = !(flags & (QLDPC_FLAG_MC_UNFUSED | QLDPC_FLAG_KERNEL_STREAM | QLDPC_FLAG_KERNEL_GENERIC)) && damping == 1.0 &&
                regular_supported(g, clip_llr, max_iter);
     if ((rc = P->d_alpha.ensure(P->alpha.size() * 8)) || (rc = P->d_prior.ensure(prior.size() * 8)) ||

@@ -14,6 +14,8 @@
 #include "common.h"
 #include "minsum_common.h"
 
+#include <cstdlib>
+
 namespace qldpc {
 
 struct WgArgs {
@@ -120,6 +122,116 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Lean variant.  PMC on the kernel above: 81 VALU + 50 SALU instructions per edge-iteration, i.e. instruction-issue bound.
+// When the launcher has verified "clean" inputs (every prior finite and not -0.0, clip finite > 0, every alpha finite > 0)
+// no posterior or message can be -0.0 and |q| is never NaN, so:
+//   * the sign of q is its sign bit (kernels.py:296 treats -0.0 as positive; it cannot occur here), collected on 32-bit words;
+//   * min1/min2 follow min2 = min(min2, max(min1,a)), min1 = min(min1,a) -- identical to the reference's compare chain
+//     (kernels.py:301-306) for non-NaN magnitudes; the first-minimum index still comes from the strict compare;
+//   * the state stores the products already signed by the row's total sign, so both passes rebuild R with one XOR.
+// NANSEL keeps the NaN -> 0 test of kernels.py:328 for graphs with degree-1 checks (their messages are +-inf).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double wmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double wmin_abs2(double a, double b) { double r; asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double wmax_abs2(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double flip_sign(double x, uint32_t signword) { return __hiloint2double(__double2hiint(x) ^ (int)signword, __double2loint(x)); }
+
+template <bool NANSEL>
+__global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
+    extern __shared__ unsigned char lds[];
+    double *V = reinterpret_cast<double *>(lds);
+    double2 *SP = reinterpret_cast<double2 *>(lds + A.offP);        // (alpha*min1, alpha*min2), both already multiplied by the row's total sign
+    uint2 *SI = reinterpret_cast<uint2 *>(lds + A.offI);            // .x = sign bits 0-31, .y = sign bits 32-55 | argmin << 24
+    int *unsat = reinterpret_cast<int *>(lds + A.offF);
+    const int m = A.m, n = A.n, max_iter = A.max_iter, tid = threadIdx.x, T = blockDim.x;
+    const double clip = A.clip, nclip = -A.clip;
+
+    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+        for (int j = tid; j < n; j += T) V[j] = A.prior[j];                                  // Q_{-1} = prior[col] (kernels.py:263-265)
+        if (tid < 2) unsat[tid] = 0;
+        bool done = false;
+        __syncthreads();
+        for (int it = 0; it <= max_iter; it++) {
+            if (A.fixed || !done) {
+                const double alpha = (it < max_iter) ? A.alpha[it] : 0.0;
+                for (int i = tid; i < m; i += T) {
+                    const int deg = A.indptr[i + 1] - A.indptr[i];
+                    const bool csyn = A.synd[b * m + i] & 1;
+                    double p1s = 0.0, p2s = 0.0;
+                    unsigned long long ip = 0ull;
+                    int argp = 127;
+                    if (it > 0 && deg > 0) {
+                        const double2 t = SP[i]; const uint2 u = SI[i];
+                        p1s = t.x; p2s = t.y; argp = (int)(u.y >> 24); ip = ((unsigned long long)(u.y & 0x00FFFFFFu) << 32) | u.x;
+                    }
+                    bool par = csyn;
+                    double min1 = INFINITY, min2 = INFINITY;
+                    int arg = 127;
+                    uint32_t nlo = 0u, nhi = 0u;
+                    for (int k = 0; k < deg; k++) {
+                        const int col = A.ell_col[(size_t)k * m + i];
+                        const double v = V[col];
+                        par ^= (v < 0.0);                                                    // kernels.py:349,356
+                        double x = v;
+                        if (it > 0) {
+                            const double mag = (k == argp) ? p2s : p1s;                      // kernels.py:313 (already carries the row sign)
+                            const double r = flip_sign(mag, (uint32_t)(ip >> k) << 31);      // R_{it-1}[e], kernels.py:311-314
+                            x = v - r;                                                       // kernels.py:325
+                            if (NANSEL) x = (x != x) ? 0.0 : x;                              // kernels.py:328-329
+                            x = wmax(wmin(x, clip), nclip);                                  // kernels.py:330-333
+                        }
+                        const uint32_t sgn = (uint32_t)__double2hiint(x) >> 31;              // x is never -0.0 or NaN here (see above)
+                        if (k < 32) nlo |= sgn << k; else nhi |= sgn << (k - 32);
+                        if (fabs(x) < min1) arg = k;                                         // kernels.py:301-304 (strict: first minimum wins)
+                        min2 = wmin(min2, wmax_abs2(min1, x));                               // kernels.py:302,305-306
+                        min1 = wmin_abs2(min1, x);
+                    }
+                    if (it >= 1 && !done && par) unsat[it & 1] = 1;                          // kernels.py:357-359
+                    if (it < max_iter && deg > 0) {                                          // kernels.py:285-286
+                        const uint32_t sp = ((uint32_t)csyn ^ (uint32_t)(__popc(nlo) + __popc(nhi))) << 31;     // total sign (kernels.py:289-299)
+                        SP[i] = make_double2(flip_sign(alpha * min1, sp), flip_sign(alpha * min2, sp));
+                        SI[i] = make_uint2(nlo, nhi | ((uint32_t)arg << 24));
+                    }
+                }
+            }
+            __syncthreads();
+            if (!done) {                                                                     // freeze test (kernels.py:361-364)
+                const bool conv = (it >= 1) && (unsat[it & 1] == 0);
+                if (conv || it == max_iter) {
+                    done = true;
+                    for (int j = tid; j < n; j += T) {
+                        const double x = (it >= 1) ? V[j] : 0.0;                             // V still holds values_{it-1}
+                        A.out_llr[b * n + j] = x;
+                        A.out_err[b * n + j] = (x < 0.0) ? 1 : 0;                            // kernels.py:349
+                    }
+                    if (tid == 0) { A.out_conv[b] = conv ? 1 : 0; A.out_iter[b] = conv ? it - 1 : max_iter - 1; }   // kernels.py:267,362
+                }
+            }
+            if (done && !A.fixed) break;
+            if (it == max_iter) break;
+            if (tid == 0) unsat[(it + 1) & 1] = 0;
+            for (int j = tid; j < n; j += T) {                                               // variable pass: values_it
+                double s = 0.0;                                                              // kernels.py:279
+                for (int d = 0; d < A.cdeg; d++) {
+                    const uint32_t e = A.ell_var[(size_t)d * n + j];
+                    if (e == 0xFFFFFFFFu) break;
+                    const int i = (int)(e >> 8), k = (int)(e & 255u);
+                    const double2 pp = SP[i];
+                    const uint2 u = SI[i];
+                    const double mag = (k == (int)(u.y >> 24)) ? pp.y : pp.x;
+                    const unsigned long long bits = ((unsigned long long)u.y << 32) | u.x;
+                    s += flip_sign(mag, (uint32_t)(bits >> k) << 31);                        // kernels.py:316, ascending check order
+                }
+                V[j] = s + A.prior[j];                                                       // kernels.py:320
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
 static size_t wg_lds_bytes(const qldpc_graph *g, int &offP, int &offI, int &offF) {
     offP = (int)round_up((int64_t)g->n * 8, 16);
     offI = offP + g->m * 16;
@@ -135,7 +247,7 @@ bool wg_supported(const qldpc_graph *g, double damping) {
 }
 
 int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
-                     double clip, int flags, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
+                     double clip, int flags, bool clean, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
     WgArgs A;
     A.m = g->m; A.n = g->n; A.max_iter = max_iter; A.fixed = (flags & QLDPC_FLAG_FIXED_ITERS) ? 1 : 0;
     A.rdeg = g->max_row_deg; A.cdeg = g->max_col_deg;
@@ -146,11 +258,20 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     static bool attr_set = false;
     if (!attr_set) {
         QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(minsum_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(minsum_wg_lean_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(minsum_wg_lean_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    bool has_deg1 = false;
+    for (int i = 0; i < g->m; i++) has_deg1 = has_deg1 || (g->indptr[i + 1] - g->indptr[i] == 1);
     const int block = (g->m > 512 || g->n > 4096) ? 1024 : 512;
     const unsigned grid = (unsigned)std::min<int64_t>(B, 256 * 2);
-    hipLaunchKernelGGL(minsum_wg_kernel, dim3(grid), dim3(block), lds, stream, A);
+    if (clean && !getenv("QLDPC_WG_GENERIC")) {
+        if (has_deg1) hipLaunchKernelGGL(minsum_wg_lean_kernel<true>, dim3(grid), dim3(block), lds, stream, A);
+        else hipLaunchKernelGGL(minsum_wg_lean_kernel<false>, dim3(grid), dim3(block), lds, stream, A);
+    } else {
+        hipLaunchKernelGGL(minsum_wg_kernel, dim3(grid), dim3(block), lds, stream, A);
+    }
     QLDPC_HIP_TRY(hipGetLastError());
     return QLDPC_OK;
 }

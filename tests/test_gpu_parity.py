@@ -92,6 +92,11 @@ def test_circuit_level_golden(L, golden, oracle, tag):
         graph = L.Graph(ip, ix, n)
         for fl in (0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM):      # auto = workgroup-per-shot kernel; streaming kernel forced
             check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), fl), g, s)
+        os.environ["QLDPC_WG_GENERIC"] = "1"                          # the generic (any-input) workgroup kernel must agree with the lean one
+        try:
+            check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), 0), g, s)
+        finally:
+            del os.environ["QLDPC_WG_GENERIC"]
         rng = np.random.default_rng(5)                                 # ragged random batch, both kernels, vs the oracle
         synd = (rng.random((37, m)) < 0.1).astype(np.int8)
         ref = oracle.minsum_decode_batch(ip, ix, n, synd, g[f"llrs_{s}"], max_iter=12, threads=0)
