@@ -6,6 +6,11 @@ import os
 import numpy as np
 import pytest
 
+try:            # this image carries two HIP runtimes (system ROCm and the one bundled with torch): import torch FIRST so that
+    import torch  # noqa: F401   # libqldpc_hip.so binds to the already-loaded runtime and both share the device
+except ImportError:
+    torch = None
+
 from conftest import ROOT, assert_llr_close
 
 pytestmark = pytest.mark.gpu
@@ -382,3 +387,65 @@ def test_builder_reproduces_reference_matrix_cache(L, tag, code, cycles):
         flr = M[f"first_logical_row{s}"]
         lip, lix, _ = L.canonical_csr(M[f"H{s}_full"][flr:flr + 12])
         assert np.array_equal(lip, d[f"H{s}_logical_indptr"]) and np.array_equal(lix, d[f"H{s}_logical_indices"])
+
+
+def test_api_edge_cases(L, oracle):
+    """Empty / degenerate inputs through every batched entry point; results against the oracle where one exists."""
+    import ctypes as C
+    from qldpc_amd.data import load_code
+    c = load_code("bb72")
+    ip, ix, n, m = c["Hx_indptr"], c["Hx_indices"], c["n"], c["m"]
+    g = L.Graph(ip, ix, n)
+    lib = L.lib()
+    # B = 0 everywhere
+    z8 = np.zeros(0, np.int8); zf = np.zeros(0)
+    L.check(lib.qldpc_gf2_spmv_batch(g.handle, C.c_int64(0), L.ptr(z8, C.c_int8), L.ptr(z8, C.c_int8)))
+    L.check(lib.qldpc_osd0_batch(g.handle, C.c_int64(0), L.ptr(z8, C.c_int8), L.ptr(zf, C.c_double), L.ptr(z8, C.c_int8), None, L.ptr(z8, C.c_int8)))
+    L.check(lib.qldpc_minsum_check_pass(g.handle, C.c_int64(0), L.ptr(zf, C.c_double), L.ptr(zf, C.c_double), C.c_double(1.0), L.ptr(zf, C.c_double), L.ptr(zf, C.c_double)))
+    assert np.array_equal(L.cc_sample_decode_tally(g, c["Lx"], 0.01, 1, 0, 0), np.zeros(16, np.int64))
+    # max_iter = 0: nothing is decoded; final_iter = -1, not converged (kernels.py:267-268 with an empty loop)
+    synd = np.zeros((5, m), np.int8); synd[1, 3] = 1
+    prior = np.full(n, 2.0)
+    for fl in (0, L.FLAG_KERNEL_GENERIC | L.FLAG_KERNEL_RESIDENT, L.FLAG_KERNEL_STREAM):
+        e, cv, v, it = L.minsum_decode_batch(g, synd, prior, 0, "dynamical", 1.0, flags=fl)
+        assert not e.any() and not cv.any() and (it == -1).all() and not v.any()
+    # negative, zero and mixed priors (not "clean": a -0.0 entry) must still match the oracle bit for bit on every kernel
+    rng = np.random.default_rng(3)
+    pri = rng.normal(0.5, 2.0, n); pri[5] = 0.0; pri[6] = -0.0; pri[7] = -3.0
+    synd = (rng.random((65, m)) < 0.2).astype(np.int8)
+    ref = oracle.minsum_decode_batch(ip, ix, n, synd, pri, max_iter=9, threads=0)
+    for fl in (0, L.FLAG_KERNEL_GENERIC | L.FLAG_KERNEL_RESIDENT, L.FLAG_KERNEL_STREAM):
+        for a, b in zip(L.minsum_decode_batch(g, synd, pri, 9, "dynamical", 1.0, flags=fl), ref):
+            assert np.array_equal(a, b, equal_nan=True)
+    # a graph without any check: every shot "converges" at iteration 0 with values = prior (kernels.py:319-364)
+    g0 = L.Graph(np.zeros(1, np.int32), np.zeros(0, np.int32), 4)
+    e, cv, v, it = L.minsum_decode_batch(g0, np.zeros((3, 0), np.int8), np.array([1.0, -2.0, 0.0, 3.0]), 5, "dynamical", 1.0)
+    assert cv.all() and (it == 0).all() and np.array_equal(v, np.tile([1.0, -2.0, 0.0, 3.0], (3, 1))) and np.array_equal(e[0], [0, 1, 0, 0])
+
+
+def test_device_pointer_entry_point(L, oracle):
+    """qldpc_minsum_decode_batch_dev on torch CUDA tensors and a non-default stream (the _dev ABI never touches host memory)."""
+    import ctypes as C
+    import torch
+    from qldpc_amd.data import load_code
+    c = load_code("bb144")
+    ip, ix, n, m = c["Hx_indptr"], c["Hx_indices"], c["n"], c["m"]
+    g = L.Graph(ip, ix, n)
+    rng = np.random.default_rng(9)
+    B = 1000
+    synd = (rng.random((B, m)) < 0.08).astype(np.int8)
+    prior = np.full(n, np.log(0.97 / 0.03))
+    ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=20, threads=0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ds = torch.from_numpy(synd).cuda(non_blocking=False); dp = torch.from_numpy(prior).cuda()
+        de = torch.empty((B, n), dtype=torch.int8, device="cuda"); dl = torch.empty((B, n), dtype=torch.float64, device="cuda")
+        dc = torch.empty(B, dtype=torch.uint8, device="cuda"); di = torch.empty(B, dtype=torch.int32, device="cuda")
+        st.synchronize()
+        L.check(L.lib().qldpc_minsum_decode_batch_dev(g.handle, C.c_int64(B), C.c_void_p(ds.data_ptr()), C.c_void_p(dp.data_ptr()), C.c_int(20),
+                                                      C.c_int(L.ALPHA_DYNAMIC), C.c_double(1.0), None, C.c_int(0), C.c_double(1.0), C.c_double(20.0),
+                                                      C.c_int(0), C.c_void_p(de.data_ptr()), C.c_void_p(dl.data_ptr()), C.c_void_p(dc.data_ptr()),
+                                                      C.c_void_p(di.data_ptr()), C.c_void_p(st.cuda_stream)))
+        st.synchronize()
+    for a, b in zip((de.cpu().numpy(), dc.cpu().numpy(), dl.cpu().numpy(), di.cpu().numpy()), ref):
+        assert np.array_equal(a, b, equal_nan=True)
