@@ -180,6 +180,27 @@ typedef struct {
 int qldpc_circuit_fault_signatures(const qldpc_circuit_desc *circuit, int sector_is_x, int32_t *ptr, uint16_t *idx, int64_t idx_cap,
                                    uint64_t *logmask, int64_t *idx_needed);
 
+/* ---- f4: the trial loops of the alpha / beta estimators, batched ------------------------------------------------------------
+ * Replaces the per-trial Python loops of estimate_alpha_alvarado (src/decoding/alpha.py:119-137),
+ * estimate_alpha_alvarado_autoregressive (alpha.py:206-255, one call per iteration index) and estimate_scopt_beta
+ * (src/decoding/scopt.py:80-134).  errors: int8[B][n], drawn by the caller (the reference draws them from the caller's numpy
+ * Generator); syndromes, decoder state, samples and histograms live on the device.
+ *   QLDPC_STATS_CHECK_MESSAGES  samples = R_flat of one check pass with alpha = 1 taken after `iters` decoder iterations that
+ *                               use alpha_k of the given alpha mode (iters = 0 is alpha.py:119-137); class = error[col[edge]].
+ *   QLDPC_STATS_POSTERIOR       samples = the posterior `values` the decoder stops with (early exit, at most `iters`
+ *                               iterations; scopt.py:88-131); class = error[j].
+ * range[0..1] = min / max over the finite samples of both classes (alpha.py:29-31), finite[c] = number of finite samples of
+ * class c (alpha.py:23-27).  qldpc_msgstats_histogram then bins them with np.histogram's rule for the given strictly increasing
+ * edges (bins + 1 values): edges[i] <= x < edges[i+1], last bin closed; hist0 / hist1: int64[bins]. */
+#define QLDPC_STATS_CHECK_MESSAGES 0
+#define QLDPC_STATS_POSTERIOR 1
+typedef struct qldpc_msgstats qldpc_msgstats;
+int qldpc_msgstats_create(const qldpc_graph *g, int64_t B, const int8_t *errors, const double *prior, int kind, int iters,
+                          int alpha_mode, double alpha_val, const double *alpha_seq, int alpha_len, double damping, double clip_llr,
+                          double *range, int64_t *finite, qldpc_msgstats **out);
+int qldpc_msgstats_histogram(qldpc_msgstats *stats, const double *edges, int bins, int64_t *hist0, int64_t *hist1);
+void qldpc_msgstats_destroy(qldpc_msgstats *stats);
+
 typedef struct qldpc_circuit_plan qldpc_circuit_plan;
 /* a13 + a14: run_trial_fast (src/noise/simulation.py:21-107) + _run_single_trial_fast and the tally
  * (src/simulation/engine.py:68-122, 450-457), batched.  gz / gx: Tanner graphs of HdecZ / HdecX; prior_*: LLRs of
@@ -191,6 +212,11 @@ int qldpc_circuit_plan_create(const qldpc_circuit_desc *circuit, const qldpc_gra
                               const double *alpha_seq_x, int alpha_len_x, double damping, double clip_llr, int use_osd, int flags,
                               int64_t batch, qldpc_circuit_plan **out);
 int qldpc_circuit_plan_run(qldpc_circuit_plan *plan, uint64_t seed, int64_t trial_begin, int64_t count, void *stream);
+/* Same pass, and additionally the per-trial verdicts in trial order: outcome[i] bit0 = z_err, bit1 = x_err of trial
+ * trial_begin + i (host buffer, `count` bytes; the call synchronises `stream`).  This is what the reference's in-order
+ * early stop needs (src/simulation/engine.py:441-464: stop at the trial where the target-th logical error occurs). */
+int qldpc_circuit_plan_run_outcomes(qldpc_circuit_plan *plan, uint64_t seed, int64_t trial_begin, int64_t count, void *stream,
+                                    uint8_t *outcome);
 int qldpc_circuit_plan_read(qldpc_circuit_plan *plan, void *stream, int clear, int64_t *tally);
 /* the sampler alone = batched run_trial_fast: sparse_z int8[count][#MeasX], true_z int8[count][k], sparse_x, true_x (host) */
 int qldpc_circuit_plan_sample(qldpc_circuit_plan *plan, uint64_t seed, int64_t trial_begin, int64_t count, int8_t *sparse_z,

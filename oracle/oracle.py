@@ -123,6 +123,34 @@ def minsum_core_sparse(indptr, indices, n, Q, ssign, alpha):
     return R, Rs
 
 
+def alpha_messages(indptr, indices, n, errors, prior, alpha_prev=(), damping=1.0, clip_llr=20.0):
+    """Trial bodies of alpha.py:119-137 / 206-255 -> R_flat[B, nnz] (unscaled messages after len(alpha_prev) iterations)."""
+    indptr, indices = _i32(indptr), _i32(indices)
+    m = indptr.size - 1
+    errors = _i8(errors).reshape(-1, n)
+    prior = _f64(prior)
+    ap = _f64(np.asarray(alpha_prev, dtype=np.float64).reshape(-1))
+    R = np.zeros((errors.shape[0], indices.size))
+    lib().orc_alpha_messages(C.c_int(m), C.c_int(n), _p(indptr, C.c_int32), _p(indices, C.c_int32), C.c_int64(errors.shape[0]),
+                             _p(errors, C.c_int8), _p(prior, C.c_double), _p(ap, C.c_double), C.c_int(ap.size), C.c_double(damping),
+                             C.c_double(clip_llr), _p(R, C.c_double))
+    return R
+
+
+def scopt_values(indptr, indices, n, errors, prior, max_iter=50, alpha=1.0, alpha_mode="dynamical", damping=1.0, clip_llr=20.0):
+    """Trial body of scopt.py:80-131 -> values[B, n]."""
+    indptr, indices = _i32(indptr), _i32(indices)
+    m = indptr.size - 1
+    errors = _i8(errors).reshape(-1, n)
+    prior = _f64(prior)
+    mode, aval, seq = _alpha_args(alpha_mode, alpha)
+    V = np.zeros((errors.shape[0], n))
+    lib().orc_scopt_values(C.c_int(m), C.c_int(n), _p(indptr, C.c_int32), _p(indices, C.c_int32), C.c_int64(errors.shape[0]),
+                           _p(errors, C.c_int8), _p(prior, C.c_double), C.c_int(max_iter), C.c_int(mode), C.c_double(aval),
+                           _p(seq, C.c_double), C.c_int(seq.size), C.c_double(damping), C.c_double(clip_llr), _p(V, C.c_double))
+    return V
+
+
 def minsum_core_dense(Q, ssign, mask, alpha):
     Q = _f64(Q)
     m, n = Q.shape

@@ -163,6 +163,87 @@ ORC_API void orc_minsum_core_sparse(int m, int n, const int32_t *indptr, const i
     }
 }
 
+/* f4: the message update shared by both estimators (alpha.py:226-244, scopt.py:101-118) */
+static void orc_estimator_q_update(int nnz, const int32_t *indices, const double *values, const double *R, double damping,
+                                   double clip, double *Q, double *Qold) {
+    for (int pos = 0; pos < nnz; pos++) {
+        double q_new = values[indices[pos]] - R[pos];
+        if (q_new != q_new) q_new = 0.0;
+        else if (q_new > clip) q_new = clip;
+        else if (q_new < -clip) q_new = -clip;
+        double q_damped = damping * q_new + (1.0 - damping) * Qold[pos];
+        if (q_damped > clip) q_damped = clip;
+        else if (q_damped < -clip) q_damped = -clip;
+        Q[pos] = q_damped;
+        Qold[pos] = q_damped;
+    }
+}
+
+/* f4: trial body of estimate_alpha_alvarado (alpha.py:119-137, n_prev = 0) and of the autoregressive estimator
+ * (alpha.py:206-255): unscaled check messages R_flat[B][nnz] after n_prev iterations with the given alphas.
+ * errors: int8[B][n]; scratch is allocated here. */
+ORC_API void orc_alpha_messages(int m, int n, const int32_t *indptr, const int32_t *indices, int64_t B, const int8_t *errors,
+                                const double *prior, const double *alpha_prev, int n_prev, double damping, double clip,
+                                double *R_out) {
+    const int nnz = indptr[m];
+    double *Q = (double *)malloc(sizeof(double) * (nnz + 1)), *Qold = (double *)malloc(sizeof(double) * (nnz + 1));
+    double *R = (double *)malloc(sizeof(double) * (nnz + 1)), *Rsum = (double *)malloc(sizeof(double) * (n + 1));
+    double *ssign = (double *)malloc(sizeof(double) * (m + 1)), *values = (double *)malloc(sizeof(double) * (n + 1));
+    for (int64_t b = 0; b < B; b++) {
+        const int8_t *e = errors + b * n;
+        for (int i = 0; i < m; i++) {
+            int s = 0;
+            for (int pos = indptr[i]; pos < indptr[i + 1]; pos++) s ^= e[indices[pos]] & 1;
+            ssign[i] = 1.0 - 2.0 * (double)s;                                              /* alpha.py:121-122 */
+        }
+        for (int pos = 0; pos < nnz; pos++) { Q[pos] = prior[indices[pos]]; Qold[pos] = Q[pos]; }
+        for (int k = 0; k < n_prev; k++) {
+            orc_minsum_core_sparse(m, n, indptr, indices, Q, ssign, alpha_prev[k], R, Rsum);
+            for (int j = 0; j < n; j++) values[j] = Rsum[j] + prior[j];
+            orc_estimator_q_update(nnz, indices, values, R, damping, clip, Q, Qold);
+        }
+        orc_minsum_core_sparse(m, n, indptr, indices, Q, ssign, 1.0, R_out + b * nnz, Rsum);
+    }
+    free(Q); free(Qold); free(R); free(Rsum); free(ssign); free(values);
+}
+
+/* f4: trial body of estimate_scopt_beta (scopt.py:80-131): posterior values[B][n] at the iteration the loop leaves */
+ORC_API void orc_scopt_values(int m, int n, const int32_t *indptr, const int32_t *indices, int64_t B, const int8_t *errors,
+                              const double *prior, int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq,
+                              int alpha_len, double damping, double clip, double *values_out) {
+    const int nnz = indptr[m];
+    double *Q = (double *)malloc(sizeof(double) * (nnz + 1)), *Qold = (double *)malloc(sizeof(double) * (nnz + 1));
+    double *R = (double *)malloc(sizeof(double) * (nnz + 1)), *Rsum = (double *)malloc(sizeof(double) * (n + 1));
+    double *ssign = (double *)malloc(sizeof(double) * (m + 1));
+    int8_t *synd = (int8_t *)malloc(m + 1);
+    for (int64_t b = 0; b < B; b++) {
+        const int8_t *e = errors + b * n;
+        double *values = values_out + b * n;
+        for (int i = 0; i < m; i++) {
+            int s = 0;
+            for (int pos = indptr[i]; pos < indptr[i + 1]; pos++) s ^= e[indices[pos]] & 1;
+            synd[i] = (int8_t)s;
+            ssign[i] = 1.0 - 2.0 * (double)s;
+        }
+        for (int pos = 0; pos < nnz; pos++) { Q[pos] = prior[indices[pos]]; Qold[pos] = Q[pos]; }
+        for (int j = 0; j < n; j++) values[j] = 0.0;
+        for (int it = 0; it < max_iter; it++) {
+            const double a = alpha_at(alpha_mode, it, alpha_val, alpha_seq, alpha_len);   /* scopt.py:89-94 */
+            orc_minsum_core_sparse(m, n, indptr, indices, Q, ssign, a, R, Rsum);
+            for (int j = 0; j < n; j++) values[j] = Rsum[j] + prior[j];
+            orc_estimator_q_update(nnz, indices, values, R, damping, clip, Q, Qold);
+            int ok = 1;                                                                   /* scopt.py:127-130 */
+            for (int i = 0; i < m && ok; i++) {
+                int s = 0;
+                for (int pos = indptr[i]; pos < indptr[i + 1]; pos++) s ^= (values[indices[pos]] < 0) ? 1 : 0;
+                ok = (s == synd[i]);
+            }
+            if (ok) break;
+        }
+    }
+    free(Q); free(Qold); free(R); free(Rsum); free(ssign); free(synd);
+}
+
 /* a4: minsum_core (kernels.py:108-136): dense-mask twin.  H is unused by the reference body. */
 ORC_API void orc_minsum_core_dense(int m, int n, const double *Q, const double *ssign, const uint8_t *mask,
                                    double alpha, double *R) {

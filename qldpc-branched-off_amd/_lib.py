@@ -22,8 +22,9 @@ EXPORTS = [
     "qldpc_bp_decode_batch", "qldpc_gf2_spmv_batch", "qldpc_gf2_eliminate", "qldpc_gf2_eliminate_packed", "qldpc_osd0_batch",
     "qldpc_noisy_circuit_batch", "qldpc_frame_sim_batch", "qldpc_sparsify_batch", "qldpc_cc_sample_decode_tally",
     "qldpc_cc_plan_create", "qldpc_cc_plan_run", "qldpc_cc_plan_read", "qldpc_cc_plan_kernel_time", "qldpc_cc_plan_destroy",
-    "qldpc_philox4x32_10", "qldpc_circuit_plan_create", "qldpc_circuit_plan_run", "qldpc_circuit_plan_read", "qldpc_circuit_plan_sample",
-    "qldpc_circuit_plan_destroy", "qldpc_circuit_fault_signatures",
+    "qldpc_philox4x32_10", "qldpc_circuit_plan_create", "qldpc_circuit_plan_run", "qldpc_circuit_plan_run_outcomes", "qldpc_circuit_plan_read", "qldpc_circuit_plan_sample",
+    "qldpc_circuit_plan_destroy", "qldpc_circuit_fault_signatures", "qldpc_msgstats_create", "qldpc_msgstats_histogram",
+    "qldpc_msgstats_destroy",
 ]
 
 
@@ -48,12 +49,13 @@ def lib():
                 L.qldpc_last_error.restype = C.c_char_p
                 for name in EXPORTS:
                     if name not in ("qldpc_last_error", "qldpc_graph_destroy", "qldpc_cc_plan_destroy", "qldpc_philox4x32_10",
-                                    "qldpc_circuit_plan_destroy"):
+                                    "qldpc_circuit_plan_destroy", "qldpc_msgstats_destroy"):
                         getattr(L, name).restype = C.c_int
                 L.qldpc_graph_destroy.restype = None
                 L.qldpc_cc_plan_destroy.restype = None
                 L.qldpc_philox4x32_10.restype = None
                 L.qldpc_circuit_plan_destroy.restype = None
+                L.qldpc_msgstats_destroy.restype = None
                 _lib = L
     return _lib
 
@@ -309,6 +311,48 @@ def circuit_fault_signatures(compiled, Lx, Lz, sector_is_x):
     return sp, idx[:need.value].copy(), lm
 
 
+STATS_CHECK_MESSAGES, STATS_POSTERIOR = 0, 1
+
+
+class MessageStats:
+    """Device-resident samples of an estimator trial loop (qldpc_msgstats_*): check messages after `iters` decoder iterations
+    (alpha.py:119-137, 206-255) or the decoder's final posteriors (scopt.py:80-134), split by the true error bit."""
+
+    def __init__(self, graph, errors, prior, kind, iters, alpha_mode="dynamical", alpha=1.0, damping=1.0, clip_llr=20.0):
+        errors = i8(errors).reshape(-1, graph.n)
+        prior = f64(prior)
+        if prior.size != graph.n:
+            raise ValueError(f"prior has {prior.size} entries, the graph has {graph.n} columns")
+        mode, aval, seq = alpha_args(alpha_mode, alpha)
+        rng, fin = np.zeros(2), np.zeros(2, np.int64)
+        self._h = C.c_void_p()
+        check(lib().qldpc_msgstats_create(graph.handle, C.c_int64(errors.shape[0]), ptr(errors, C.c_int8), ptr(prior, C.c_double),
+                                          C.c_int(kind), C.c_int(iters), C.c_int(mode), C.c_double(aval), ptr(seq, C.c_double),
+                                          C.c_int(seq.size), C.c_double(damping), C.c_double(clip_llr), ptr(rng, C.c_double),
+                                          ptr(fin, C.c_int64), C.byref(self._h)))
+        self.range = (float(rng[0]), float(rng[1]))
+        self.finite = (int(fin[0]), int(fin[1]))
+
+    def histogram(self, edges):
+        """Counts per bin for the two classes, np.histogram's bin rule -> (int64[bins], int64[bins])."""
+        edges = f64(edges)
+        bins = edges.size - 1
+        h0, h1 = np.zeros(bins, np.int64), np.zeros(bins, np.int64)
+        check(lib().qldpc_msgstats_histogram(self._h, ptr(edges, C.c_double), C.c_int(bins), ptr(h0, C.c_int64), ptr(h1, C.c_int64)))
+        return h0, h1
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().qldpc_msgstats_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CircuitPlan:
     """Circuit-level Monte-Carlo plan (qldpc_circuit_plan_*): Philox fault sampling through precomputed fault signatures,
     decode of both sectors, OSD-0, logical comparison and tally, all on the device."""
@@ -342,6 +386,13 @@ class CircuitPlan:
 
     def run(self, seed, trial_begin, count, stream=0):
         check(lib().qldpc_circuit_plan_run(self._h, C.c_uint64(seed), C.c_int64(trial_begin), C.c_int64(count), C.c_void_p(stream)))
+
+    def run_outcomes(self, seed, trial_begin, count, stream=0):
+        """run() + the per-trial verdicts in trial order: uint8[count], bit0 = z_err, bit1 = x_err."""
+        out = np.zeros(max(int(count), 0), np.uint8)
+        check(lib().qldpc_circuit_plan_run_outcomes(self._h, C.c_uint64(seed), C.c_int64(trial_begin), C.c_int64(count), C.c_void_p(stream),
+                                                    ptr(out, C.c_uint8)))
+        return out
 
     def read(self, stream=0, clear=False):
         tally = np.zeros(TALLY_SLOTS, np.int64)

@@ -140,7 +140,8 @@ __device__ __forceinline__ void judge_sector(const JudgeSector &S, int64_t b, in
     bad = bd != 0;
 }
 
-__global__ __launch_bounds__(256) void circuit_judge_kernel(int64_t B, JudgeSector Z, JudgeSector X, unsigned long long *__restrict__ tally) {
+__global__ __launch_bounds__(256) void circuit_judge_kernel(int64_t B, JudgeSector Z, JudgeSector X, unsigned long long *__restrict__ tally,
+                                                            uint8_t *__restrict__ outcome) {
     __shared__ unsigned long long acc[QLDPC_TALLY_SLOTS];
     if (threadIdx.x < QLDPC_TALLY_SLOTS) acc[threadIdx.x] = 0ull;
     __syncthreads();
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256) void circuit_judge_kernel(int64_t B, JudgeSect
         judge_sector(Z, b, lane, ze, zn, zb);
         judge_sector(X, b, lane, xe, xn, xb);
         if (lane == 0) {
+            if (outcome) outcome[b] = (uint8_t)((ze ? 1 : 0) | (xe ? 2 : 0));               // (z_err, x_err) of engine.py:117-122
             atomicAdd(&acc[QLDPC_TALLY_TRIALS], 1ull);
             if (ze) atomicAdd(&acc[QLDPC_TALLY_Z_ERR], 1ull);
             if (xe) atomicAdd(&acc[QLDPC_TALLY_X_ERR], 1ull);
@@ -191,11 +193,11 @@ struct qldpc_circuit_plan {
     DevBuf d_loc_type, d_zptr, d_zidx, d_zlog, d_xptr, d_xidx, d_xlog;
     DevBuf d_alpha_z, d_alpha_x, d_prior_z, d_prior_x, d_lm_z, d_lm_x;
     DevBuf d_syn_z, d_syn_x, d_true_z, d_true_x, d_det_z, d_det_x, d_llr_z, d_llr_x, d_conv_z, d_conv_x, d_iter_z, d_iter_x;
-    DevBuf d_list, d_count, d_tally;
+    DevBuf d_list, d_count, d_tally, d_outcome;
     std::vector<DevBuf *> all() {
         return {&d_loc_type, &d_zptr, &d_zidx, &d_zlog, &d_xptr, &d_xidx, &d_xlog, &d_alpha_z, &d_alpha_x, &d_prior_z, &d_prior_x, &d_lm_z, &d_lm_x,
                 &d_syn_z, &d_syn_x, &d_true_z, &d_true_x, &d_det_z, &d_det_x, &d_llr_z, &d_llr_x, &d_conv_z, &d_conv_x, &d_iter_z, &d_iter_x,
-                &d_list, &d_count, &d_tally};
+                &d_list, &d_count, &d_tally, &d_outcome};
     }
 };
 
@@ -419,12 +421,11 @@ static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B,
     return QLDPC_OK;
 }
 
-QLDPC_EXPORT int qldpc_circuit_plan_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin, int64_t count, void *stream) {
-    QLDPC_REQUIRE(P != nullptr, "plan is NULL");
-    QLDPC_REQUIRE(count >= 0 && trial_begin >= 0, "negative trial range");
+// one pass over [trial_begin, trial_begin + count); `outcome` (host, may be NULL) receives bit0 = z_err, bit1 = x_err per trial
+static int circuit_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin, int64_t count, hipStream_t s, uint8_t *outcome) {
     int rc = use_device(P->device);
     if (rc != QLDPC_OK) return rc;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (outcome && (rc = P->d_outcome.ensure((size_t)P->batch)) != QLDPC_OK) return rc;
     for (int64_t off = 0; off < count; off += P->batch) {
         const int64_t B = std::min<int64_t>(P->batch, count - off);
         if ((rc = launch_sampler(P, seed, trial_begin + off, B, s)) != QLDPC_OK) return rc;
@@ -434,10 +435,29 @@ QLDPC_EXPORT int qldpc_circuit_plan_run(qldpc_circuit_plan *P, uint64_t seed, in
                       P->d_conv_z.as<uint8_t>(), P->d_iter_z.as<int32_t>(), P->d_true_z.as<unsigned long long>()};
         JudgeSector X{P->gx->m, P->gx->n, P->gx->d_indptr, P->gx->d_indices, P->d_lm_x.as<uint64_t>(), P->d_syn_x.as<int8_t>(), P->d_det_x.as<int8_t>(),
                       P->d_conv_x.as<uint8_t>(), P->d_iter_x.as<int32_t>(), P->d_true_x.as<unsigned long long>()};
-        hipLaunchKernelGGL(circuit_judge_kernel, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, B, Z, X, P->d_tally.as<unsigned long long>());
+        hipLaunchKernelGGL(circuit_judge_kernel, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, B, Z, X, P->d_tally.as<unsigned long long>(),
+                           outcome ? P->d_outcome.as<uint8_t>() : (uint8_t *)nullptr);
         QLDPC_HIP_TRY(hipGetLastError());
+        if (outcome) {
+            QLDPC_HIP_TRY(hipMemcpyAsync(outcome + off, P->d_outcome.p, (size_t)B, hipMemcpyDeviceToHost, s));
+            QLDPC_HIP_TRY(hipStreamSynchronize(s));
+        }
     }
     return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_circuit_plan_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin, int64_t count, void *stream) {
+    QLDPC_REQUIRE(P != nullptr, "plan is NULL");
+    QLDPC_REQUIRE(count >= 0 && trial_begin >= 0, "negative trial range");
+    return circuit_run(P, seed, trial_begin, count, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+QLDPC_EXPORT int qldpc_circuit_plan_run_outcomes(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin, int64_t count, void *stream,
+                                                 uint8_t *outcome) {
+    QLDPC_REQUIRE(P != nullptr, "plan is NULL");
+    QLDPC_REQUIRE(count >= 0 && trial_begin >= 0, "negative trial range");
+    QLDPC_REQUIRE(count == 0 || outcome != nullptr, "outcome is NULL");
+    return circuit_run(P, seed, trial_begin, count, reinterpret_cast<hipStream_t>(stream), outcome);
 }
 
 QLDPC_EXPORT int qldpc_circuit_plan_read(qldpc_circuit_plan *P, void *stream, int clear, int64_t *tally) {

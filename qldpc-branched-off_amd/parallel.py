@@ -32,6 +32,33 @@ def allreduce_tally(tally, device=None, group=None):
     return tt.cpu().numpy()
 
 
+def gather_in_shot_order(local, total, group=None):
+    """Concatenate the per-rank uint8 arrays of a `shard_range` split back into global shot order (all ranks get the result)."""
+    import torch
+    import torch.distributed as dist
+    local = np.ascontiguousarray(local, dtype=np.uint8)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local.copy()
+    world = dist.get_world_size(group)
+    width = -(-int(total) // world)                       # the largest shard; shorter shards are padded
+    buf = torch.zeros(max(width, 1), dtype=torch.uint8)
+    buf[:local.size] = torch.from_numpy(local.copy())
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    parts = [torch.empty_like(buf, device=dev) for _ in range(world)]
+    dist.all_gather(parts, buf.to(dev), group=group)
+    return np.concatenate([parts[r].cpu().numpy()[:shard_range(total, r, world)[1]] for r in range(world)])
+
+
+def cut_at_target(outcomes, errors_so_far, target):
+    """In-order early stop (reference engine.py:441-464): the number of leading trials to count so that the running total of
+    logical errors reaches `target` exactly at the last counted trial; len(outcomes) when the target is not reached."""
+    bad = np.flatnonzero(np.asarray(outcomes) != 0)
+    need = int(target) - int(errors_so_far)
+    if need <= 0:
+        return 0
+    return int(bad[need - 1]) + 1 if bad.size >= need else int(np.asarray(outcomes).size)
+
+
 def run_sharded(total_shots, local_tally_fn, rank=None, world=None, shot_offset=0, device=None, group=None):
     """Every rank tallies its own shot range with `local_tally_fn(shot_begin, count) -> int64[16]`, then one all-reduce."""
     import torch.distributed as dist

@@ -49,3 +49,62 @@ def assert_llr_close(a, b, tol=1e-5):
     assert np.array_equal(a[inf], b[inf])
     if fin.any():
         assert np.max(np.abs(a[fin] - b[fin])) <= tol
+
+
+# ---- f4 estimator fixtures (tests/golden/estimators.npz, produced by the reference's alpha.py / scopt.py) ----------------
+class ReplayRng:
+    """Stands in for the numpy Generator of the golden run: `random(shape)` returns 0.0 where the recorded draw was below the
+    error rate and 1.0 elsewhere, in the recorded order (the fixture stores the error bits, not the uniform doubles)."""
+
+    def __init__(self, error_bits):
+        self.bits = np.asarray(error_bits, dtype=bool)
+        self.row = 0
+
+    def random(self, shape):
+        rows, n = (1, int(shape)) if np.isscalar(shape) else (int(shape[0]), int(shape[1]))
+        out = np.where(self.bits[self.row:self.row + rows, :n], 0.0, 1.0)
+        assert out.shape[0] == rows, "estimator drew more patterns than the golden run"
+        self.row += rows
+        return out[0] if np.isscalar(shape) else out
+
+
+def estimator_cases(G):
+    """-> list of dicts describing every case of estimators.npz with its graph in CSR form (from the package data files)."""
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd.data import load_code, load_circuit_matrices
+    c = load_code("bb72")
+    d = load_circuit_matrices("circ72")
+    graphs = {"bb72": (c["Hx_indptr"], c["Hx_indices"], int(c["n"])),
+              "circ72": (d["HdecZ_indptr"], d["HdecZ_indices"], int(d["HdecZ_shape"][1]))}
+    cases = []
+    for name in [str(x) for x in G["cases"]]:
+        g = lambda k: G[f"{name}__{k}"]          # noqa: E731
+        indptr, indices, n = graphs[str(g("graph"))]
+        case = dict(name=name, kind=str(g("kind")), indptr=indptr, indices=indices, n=n, p=float(g("p")), prior=G[f"prior__{str(g('prior'))}"],
+                    errors=np.unpackbits(g("errors"), axis=1)[:, :n].astype(np.int8), trials=int(g("trials")), bins=int(g("bins")),
+                    hist=g("hist"), edges=g("edges"))
+        for k in ("iters", "damping", "clip", "alpha_mode", "alpha"):
+            if f"{name}__{k}" in G:
+                v = g(k)
+                case[k] = str(v) if k == "alpha_mode" else (v if v.ndim else v.item())
+        case["out"] = {k.split("__out_")[1]: G[k] for k in G if k.startswith(f"{name}__out_")}
+        cases.append(case)
+    return cases
+
+
+def reference_fit(samples, bits, bins, flip=False):
+    """The reference's post-processing (alpha.py:23-66 / scopt.py:139-166) on explicit samples -> (slope, r2, hist0, hist1, edges)."""
+    from scipy.optimize import curve_fit
+    s0, s1 = samples[bits == 0], samples[bits == 1]
+    s0, s1 = s0[np.isfinite(s0)], s1[np.isfinite(s1)]
+    rng = (min(s0.min(), s1.min()), max(s0.max(), s1.max()))
+    h0, edges = np.histogram(s0, bins=bins, range=rng, density=True)
+    h1, _ = np.histogram(s1, bins=bins, range=rng, density=True)
+    centres = (edges[:-1] + edges[1:]) / 2.0
+    ok = (h0 > 0) & (h1 > 0)
+    y = np.log(h1[ok] / h0[ok]) if flip else np.log(h0[ok] / h1[ok])
+    x = centres[ok]
+    popt, _ = curve_fit(lambda t, a: a * t, x, y)
+    fit = popt[0] * x
+    tot = np.sum((y - np.mean(y)) ** 2)
+    return popt[0], 1.0 - (np.sum((y - fit) ** 2) / tot if tot > 0 else np.nan), h0, h1, edges

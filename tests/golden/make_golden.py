@@ -38,6 +38,8 @@ from src.codes.bb_code import BBCodeCircuit  # noqa: E402
 from src.noise.compiled import CompiledCircuit  # noqa: E402
 from src.noise import kernels as NK  # noqa: E402
 from src.noise.simulation import run_trial_fast  # noqa: E402
+from src.decoding import alpha as ALPHA  # noqa: E402
+from src.decoding import scopt as SCOPT  # noqa: E402
 
 DATA = os.path.join(REPO, "qldpc-branched-off_amd", "data")
 CODES = {
@@ -409,11 +411,107 @@ def gen_circuit_decode(tag, noise, ndec, n_osd, max_iter):
     save(f"{tag}_decode", **out)
 
 
+class RecordingRng:
+    """Wraps a numpy Generator and keeps every `random(n)` draw, so the fixture can store the error patterns the reference used."""
+
+    def __init__(self, seed):
+        self.gen = np.random.default_rng(seed)
+        self.draws = []
+
+    def random(self, n):
+        r = self.gen.random(n)
+        self.draws.append(r.copy())
+        return r
+
+
+def spy_histograms(module, fn, *args, **kw):
+    """Run fn and also return the (hist, edges) pairs np.histogram produced inside it (observed, not altered)."""
+    real = np.histogram
+    seen = []
+
+    def spy(a, *aa, **kk):
+        r = real(a, *aa, **kk)
+        seen.append((np.asarray(r[0]).copy(), np.asarray(r[1]).copy()))
+        return r
+    module.np.histogram = spy
+    try:
+        out = fn(*args, **kw)
+    finally:
+        module.np.histogram = real
+    return out, seen
+
+
+def gen_estimators():
+    """f4: estimate_alpha_alvarado / _autoregressive (alpha.py) and estimate_scopt_beta (scopt.py) with recorded draws."""
+    out = {}
+    names = []
+    c = load_code("bb72")
+    Hbb = np.asarray(c["Hx"], dtype=np.int64)
+    n_bb = Hbb.shape[1]
+    q = np.random.default_rng(5).uniform(0.01, 0.12, n_bb)
+    priors_bb = {"uni": np.full(n_bb, np.log((1 - 0.05) / 0.05)), "mix": np.log((1 - q) / q)}
+    m72 = np.load(os.path.join(REF, CACHE["circ72"][0]))
+    Hc72 = np.asarray(m72["HdecZ"], dtype=np.int64)
+    graphs = {"bb72": (Hbb, 0.05), "circ72": (Hc72, 0.005)}
+    priors = {"bb72_uni": priors_bb["uni"], "bb72_mix": priors_bb["mix"], "circ72_chan": prior_llrs(m72["channel_probsZ"])}
+
+    def record(name, gname, pname, kind, rng, result, hists, **params):
+        H, p = graphs[gname]
+        draws = np.array(rng.draws)
+        names.append(name)
+        out[f"{name}__graph"] = np.array(gname)
+        out[f"{name}__prior"] = np.array(pname)
+        out[f"{name}__kind"] = np.array(kind)
+        out[f"{name}__p"] = np.float64(p)
+        out[f"{name}__errors"] = np.packbits(draws < p, axis=1)                 # [calls * trials][ceil(n/8)]
+        for k, v in params.items():
+            out[f"{name}__{k}"] = np.asarray(v)
+        for k, v in result.items():
+            out[f"{name}__out_{k}"] = np.asarray(v, dtype=np.float64)
+        out[f"{name}__hist"] = np.array([h for h, _ in hists], dtype=np.float64)   # [2 * fits][bins] density histograms (class 0, class 1, ...)
+        out[f"{name}__edges"] = np.array([e for _, e in hists][::2], dtype=np.float64)
+        print(f"    {name}: {result}")
+
+    for gname, pname, trials, bins, seed in (("bb72", "bb72_uni", 300, 50, 11), ("bb72", "bb72_mix", 300, 40, 12), ("circ72", "circ72_chan", 24, 50, 13)):
+        H, p = graphs[gname]
+        rng = RecordingRng(seed)
+        t0 = time.time()
+        (a, r2), hists = spy_histograms(ALPHA, ALPHA.estimate_alpha_alvarado, csr_matrix(H), p, trials=trials, bins=bins, rng=rng, llrs=priors[pname])
+        record(f"alv_{pname}", gname, pname, "alvarado", rng, {"alpha": a, "r2": r2}, hists, trials=trials, bins=bins)
+        print(f"      {time.time() - t0:.1f}s")
+    for gname, pname, trials, bins, iters, damping, clip, seed in (("bb72", "bb72_mix", 150, 50, 4, 1.0, 20.0, 21), ("bb72", "bb72_uni", 150, 30, 3, 0.7, 6.0, 22),
+                                                                   ("circ72", "circ72_chan", 12, 50, 2, 1.0, 20.0, 23)):
+        H, p = graphs[gname]
+        rng = RecordingRng(seed)
+        t0 = time.time()
+        (av, rv), hists = spy_histograms(ALPHA, ALPHA.estimate_alpha_alvarado_autoregressive, csr_matrix(H), p, maxIter=iters, trials=trials, bins=bins,
+                                         damping=damping, clip_llr=clip, rng=rng, llrs=priors[pname])
+        record(f"auto_{pname}", gname, pname, "autoregressive", rng, {"alpha": av, "r2": rv}, hists, trials=trials, bins=bins, iters=iters, damping=damping, clip=clip)
+        print(f"      {time.time() - t0:.1f}s")
+    for tag, gname, pname, trials, bins, iters, mode, alpha, damping, clip, seed in (
+            ("dyn", "bb72", "bb72_mix", 150, 50, 20, "dynamical", 1.0, 1.0, 20.0, 31),
+            ("alv", "bb72", "bb72_uni", 150, 50, 12, "alvarado", 0.8, 0.8, 8.0, 32),
+            ("seq", "bb72", "bb72_mix", 150, 25, 9, "alvarado-autoregressive", np.array([0.7, 0.8, 0.9]), 1.0, 20.0, 33),
+            ("dyn", "circ72", "circ72_chan", 10, 50, 8, "dynamical", 1.0, 1.0, 20.0, 34)):
+        H, p = graphs[gname]
+        rng = RecordingRng(seed)
+        t0 = time.time()
+        (b, r2), hists = spy_histograms(SCOPT, SCOPT.estimate_scopt_beta, csr_matrix(H), p, trials=trials, bins=bins, alpha=alpha, alpha_mode=mode,
+                                        maxIter=iters, damping=damping, clip_llr=clip, rng=rng, llrs=priors[pname])
+        record(f"scopt_{tag}_{pname}", gname, pname, "scopt", rng, {"beta": b, "r2": r2}, hists, trials=trials, bins=bins, iters=iters, alpha_mode=mode,
+               alpha=alpha, damping=damping, clip=clip)
+        print(f"      {time.time() - t0:.1f}s")
+    out["cases"] = np.array(names)
+    for k, v in priors.items():
+        out[f"prior__{k}"] = v
+    save("estimators", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["data", "steane", "bb", "core", "gf2", "circ72", "circ144"]
+    todo = a.only.split(",") if a.only else ["data", "steane", "bb", "core", "gf2", "circ72", "circ144", "estimators"]
     t0 = time.time()
     if "data" in todo:
         print("[data]"); pack_data()
@@ -431,6 +529,8 @@ def main():
         print("[circ72]"); nz = gen_noise("circ72", 8); gen_circuit_decode("circ72", nz, 4, 3, 50)
     if "circ144" in todo:
         print("[circ144]"); nz = gen_noise("circ144", 4); gen_circuit_decode("circ144", nz, 2, 1, 50)
+    if "estimators" in todo:
+        print("[estimators]"); gen_estimators()
     print(f"done in {time.time() - t0:.0f}s")
 
 

@@ -364,6 +364,17 @@ def test_run_simulation_mirror(L, oracle, golden):
     assert np.array_equal(res3["tally"], ref)
     with pytest.raises(NotImplementedError):
         run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=10, num_cycles=6, scopt=True, **bb)
+    # in-order early stop (engine.py:441-464): the run ends AT the trial that brings the error count to the target
+    per_trial = np.stack([oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], 0.005, 31337, i, 1, max_iter=50, threads=1) for i in range(150)])
+    bad = np.flatnonzero(per_trial[:, 3])
+    assert bad.size >= 4
+    for target in (1, 3, bad.size, bad.size + 5):
+        r = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=150, num_cycles=6, maxIter=50,
+                           precomputed_matrices=load_precomputed_matrices("circ72"), base_seed=31337, batch=32,
+                           target_logical_errors=target, **bb)
+        stop = int(bad[target - 1]) + 1 if target <= bad.size else 150
+        assert r["num_trials"] == stop and r["logical_errors"] == int(per_trial[:stop, 3].sum())
+        assert r["z_logical_error_rate"] == per_trial[:stop, 1].sum() / stop and r["x_logical_error_rate"] == per_trial[:stop, 2].sum() / stop
 
 
 @pytest.mark.parametrize("tag,code,cycles", [("circ72", "bb72", 6), ("circ144", "bb144", 12)])
@@ -449,3 +460,85 @@ def test_device_pointer_entry_point(L, oracle):
         st.synchronize()
     for a, b in zip((de.cpu().numpy(), dc.cpu().numpy(), dl.cpu().numpy(), di.cpu().numpy()), ref):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_estimators_golden(L, golden):
+    """f4: estimate_alpha_alvarado / _autoregressive / estimate_scopt_beta on the GPU against the values the REFERENCE produced from
+    the same error patterns (tests/golden/estimators.npz): identical histograms, factors within 1e-9 (scipy's fit on equal inputs)."""
+    from conftest import ReplayRng, estimator_cases
+    from qldpc_amd.decoding.alpha import estimate_alpha_alvarado, estimate_alpha_alvarado_autoregressive
+    from qldpc_amd.decoding.scopt import estimate_scopt_beta
+    from qldpc_amd.decoding._fit import class_densities
+    from scipy.sparse import csr_matrix
+    for c in estimator_cases(golden("estimators")):
+        m = len(c["indptr"]) - 1
+        H = csr_matrix((np.ones(len(c["indices"]), np.int8), c["indices"], c["indptr"]), shape=(m, c["n"]))
+        g = L.graph_for(*L.canonical_csr(H)[:2], c["n"])
+        if c["kind"] == "alvarado":
+            a, r2 = estimate_alpha_alvarado(H, c["p"], trials=c["trials"], bins=c["bins"], rng=ReplayRng(c["errors"]), llrs=c["prior"])
+            assert abs(a - c["out"]["alpha"]) <= 1e-9 and abs(r2 - c["out"]["r2"]) <= 1e-9, c["name"]
+            st = L.MessageStats(g, c["errors"], c["prior"], L.STATS_CHECK_MESSAGES, 0)
+            f0, f1, edges = class_densities(st, c["bins"], "alpha")
+            st.close()
+            assert np.array_equal(f0, c["hist"][0]) and np.array_equal(f1, c["hist"][1]) and np.array_equal(edges, c["edges"][0])
+        elif c["kind"] == "autoregressive":
+            av, rv = estimate_alpha_alvarado_autoregressive(H, c["p"], maxIter=c["iters"], trials=c["trials"], bins=c["bins"], damping=c["damping"],
+                                                            clip_llr=c["clip"], rng=ReplayRng(c["errors"]), llrs=c["prior"])
+            assert av.shape == c["out"]["alpha"].shape and np.max(np.abs(av - c["out"]["alpha"])) <= 1e-9, (c["name"], av, c["out"]["alpha"])
+            assert np.max(np.abs(rv - c["out"]["r2"])) <= 1e-9
+            k = c["iters"] - 1                  # the deepest fit, fed with the reference's own previous factors
+            E = c["errors"][k * c["trials"]:(k + 1) * c["trials"]]
+            st = L.MessageStats(g, E, c["prior"], L.STATS_CHECK_MESSAGES, k, alpha_mode="alvarado-autoregressive", alpha=c["out"]["alpha"][:k],
+                                damping=c["damping"], clip_llr=c["clip"])
+            f0, f1, edges = class_densities(st, c["bins"], "alpha")
+            st.close()
+            assert np.array_equal(f0, c["hist"][2 * k]) and np.array_equal(f1, c["hist"][2 * k + 1]) and np.array_equal(edges, c["edges"][k])
+        else:
+            b, r2 = estimate_scopt_beta(H, c["p"], trials=c["trials"], bins=c["bins"], alpha=c["alpha"], alpha_mode=c["alpha_mode"], maxIter=c["iters"],
+                                        damping=c["damping"], clip_llr=c["clip"], rng=ReplayRng(c["errors"]), llrs=c["prior"])
+            assert abs(b - c["out"]["beta"]) <= 1e-9 and abs(r2 - c["out"]["r2"]) <= 1e-9, c["name"]
+
+
+def test_estimator_statistics_vs_oracle(L, oracle):
+    """f4 at a larger size: range, finite counts and both histograms of the device trial loops equal the oracle's samples binned by numpy
+    (bit-exact counts), for check messages after 0 / 3 iterations and for posteriors; includes a degree-1 check (infinite messages)."""
+    from qldpc_amd.data import load_code
+    rng = np.random.default_rng(77)
+    c = load_code("bb144")
+    ip, ix, n = c["Hx_indptr"], c["Hx_indices"], int(c["n"])
+    g = L.graph_for(ip, ix, n)
+    q = rng.uniform(0.005, 0.09, n)
+    prior = np.log((1 - q) / q)
+    E = (rng.random((3000, n)) < 0.04).astype(np.int8)
+    cols = np.asarray(ix)
+
+    def check(stats, samples, bits, bins):
+        fin = np.isfinite(samples)
+        assert stats.finite == (int(np.count_nonzero(fin & (bits == 0))), int(np.count_nonzero(fin & (bits == 1))))
+        assert stats.range == (samples[fin].min(), samples[fin].max())
+        edges = np.histogram_bin_edges(np.zeros(0), bins=bins, range=stats.range)
+        h0, h1 = stats.histogram(edges)
+        assert np.array_equal(h0, np.histogram(samples[fin & (bits == 0)], bins=bins, range=stats.range)[0])
+        assert np.array_equal(h1, np.histogram(samples[fin & (bits == 1)], bins=bins, range=stats.range)[0])
+        stats.close()
+
+    for prev, damping, clip in (((), 1.0, 20.0), ((0.6, 0.75, 0.85), 0.8, 7.5)):
+        R = oracle.alpha_messages(ip, ix, n, E, prior, alpha_prev=prev, damping=damping, clip_llr=clip)
+        mode, alpha = ("alvarado-autoregressive", np.array(prev)) if prev else ("dynamical", 1.0)
+        check(L.MessageStats(g, E, prior, L.STATS_CHECK_MESSAGES, len(prev), alpha_mode=mode, alpha=alpha, damping=damping, clip_llr=clip),
+              R.ravel(), E[:, cols].ravel(), 64)
+    for mode, alpha, iters in (("dynamical", 1.0, 30), ("alvarado", 0.75, 10), ("alvarado-autoregressive", np.array([0.6, 0.8]), 7)):
+        V = oracle.scopt_values(ip, ix, n, E, prior, max_iter=iters, alpha=alpha, alpha_mode=mode)
+        check(L.MessageStats(g, E, prior, L.STATS_POSTERIOR, iters, alpha_mode=mode, alpha=alpha), V.ravel(), E.ravel(), 50)
+    # a graph with a degree-1 check: its message is +-inf (min over an empty set) and must be dropped like np.isfinite does
+    ip2 = np.array([0, 1, 3, 6], np.int32); ix2 = np.array([0, 0, 1, 1, 2, 3], np.int32)
+    g2 = L.Graph(ip2, ix2, 4)
+    E2 = (rng.random((500, 4)) < 0.2).astype(np.int8)
+    pr2 = np.array([1.5, 2.5, 0.5, 3.0])
+    R2 = oracle.alpha_messages(ip2, ix2, 4, E2, pr2)
+    assert np.isinf(R2).any()
+    check(L.MessageStats(g2, E2, pr2, L.STATS_CHECK_MESSAGES, 0), R2.ravel(), E2[:, ix2].ravel(), 10)
+    # argument errors mirror the reference
+    with pytest.raises(ValueError):
+        from qldpc_amd.decoding.alpha import estimate_alpha_alvarado
+        estimate_alpha_alvarado(np.eye(3, dtype=np.int8), 0.7, llrs=np.ones(3))

@@ -199,3 +199,34 @@ def test_philox_circuit_trial_equals_explicit_random_path(oracle, golden):
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
         assert (rv == 0).sum() > 0
+
+
+def test_estimator_trial_loops(oracle, golden):
+    """f4: the oracle's restatement of the alpha / beta estimator trial loops (alpha.py:119-137, 206-255; scopt.py:80-134), followed by
+    the reference's own numpy post-processing, reproduces the histograms and fitted factors the reference produced."""
+    from conftest import estimator_cases, reference_fit
+    seen = set()
+    for c in estimator_cases(golden("estimators")):
+        seen.add(c["kind"])
+        cols = np.asarray(c["indices"])
+        if c["kind"] == "alvarado":
+            R = oracle.alpha_messages(c["indptr"], c["indices"], c["n"], c["errors"], c["prior"])
+            a, r2, h0, h1, edges = reference_fit(R.ravel(), c["errors"][:, cols].ravel(), c["bins"])
+            assert np.array_equal(h0, c["hist"][0]) and np.array_equal(h1, c["hist"][1]) and np.array_equal(edges, c["edges"][0]), c["name"]
+            assert abs(a - c["out"]["alpha"]) <= 1e-9 and abs(r2 - c["out"]["r2"]) <= 1e-9
+        elif c["kind"] == "autoregressive":
+            alphas = []
+            for k in range(c["iters"]):
+                E = c["errors"][k * c["trials"]:(k + 1) * c["trials"]]
+                R = oracle.alpha_messages(c["indptr"], c["indices"], c["n"], E, c["prior"], alpha_prev=alphas, damping=c["damping"], clip_llr=c["clip"])
+                a, r2, h0, h1, edges = reference_fit(R.ravel(), E[:, cols].ravel(), c["bins"])
+                assert np.array_equal(h0, c["hist"][2 * k]) and np.array_equal(h1, c["hist"][2 * k + 1]) and np.array_equal(edges, c["edges"][k]), (c["name"], k)
+                assert abs(a - c["out"]["alpha"][k]) <= 1e-9 and abs(r2 - c["out"]["r2"][k]) <= 1e-9
+                alphas.append(float(c["out"]["alpha"][k]))          # the reference's own value, so later iterations see identical inputs
+        else:
+            V = oracle.scopt_values(c["indptr"], c["indices"], c["n"], c["errors"], c["prior"], max_iter=c["iters"], alpha=c["alpha"],
+                                    alpha_mode=c["alpha_mode"], damping=c["damping"], clip_llr=c["clip"])
+            b, r2, h0, h1, edges = reference_fit(V.ravel(), c["errors"].ravel(), c["bins"], flip=True)
+            assert np.array_equal(h0, c["hist"][0]) and np.array_equal(h1, c["hist"][1]) and np.array_equal(edges, c["edges"][0]), c["name"]
+            assert abs(b - c["out"]["beta"]) <= 1e-9 and abs(r2 - c["out"]["r2"]) <= 1e-9
+    assert seen == {"alvarado", "autoregressive", "scopt"}

@@ -31,6 +31,11 @@ def _worker(rank, world, port, total, out_dir):
         return orc.cc_sample_decode_tally(c["Hx_indptr"], c["Hx_indices"], c["n"], c["Lx"], 0.04, 99, begin, count, max_iter=20, threads=1)
     t = parallel.run_sharded(total, local)
     np.save(os.path.join(out_dir, f"tally_{rank}.npy"), t)
+    # per-trial verdicts gathered back into shot order (the in-order early stop of engine.py:441-464)
+    for round_total in (0, 1, world - 1, 257):
+        begin, count = parallel.shard_range(round_total, rank, world)
+        mine = ((np.arange(begin, begin + count) * 7919) % 11 == 0).astype(np.uint8) * (1 + (np.arange(begin, begin + count) % 3 == 0))
+        np.save(os.path.join(out_dir, f"verdicts_{round_total}_{rank}.npy"), parallel.gather_in_shot_order(mine, round_total))
     dist.destroy_process_group()
 
 
@@ -47,6 +52,20 @@ def test_sharded_tally_equals_single_process(tmp_path, oracle, world):
         t = np.load(os.path.join(str(tmp_path), f"tally_{r}.npy"))
         assert np.array_equal(t, ref), (r, t.tolist(), ref.tolist())
     assert ref[0] == total and ref[3] > 0
+    for round_total in (0, 1, world - 1, 257):
+        idx = np.arange(round_total)
+        want = ((idx * 7919) % 11 == 0).astype(np.uint8) * (1 + (idx % 3 == 0))
+        for r in range(world):
+            assert np.array_equal(np.load(os.path.join(str(tmp_path), f"verdicts_{round_total}_{r}.npy")), want)
+
+
+def test_cut_at_target():
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd.parallel import cut_at_target
+    v = np.array([0, 1, 0, 0, 2, 3, 0, 1], np.uint8)
+    assert cut_at_target(v, 0, 1) == 2 and cut_at_target(v, 0, 2) == 5 and cut_at_target(v, 0, 4) == 8
+    assert cut_at_target(v, 0, 5) == 8 and cut_at_target(v, 3, 4) == 2 and cut_at_target(v, 4, 4) == 0
+    assert cut_at_target(np.zeros(0, np.uint8), 0, 1) == 0
 
 
 def test_shard_range_properties():
