@@ -122,6 +122,13 @@ int qldpc_gf2_eliminate_packed(int64_t B, int m, int n, int nwords, uint64_t *A,
  * ascending index (np.argsort's default kind leaves ties implementation-defined, osd.py:12). solution int8[B][n]. */
 int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *llr, const int8_t *hard,
                      const int32_t *ordering, int8_t *solution);
+/* f1: performOSD_enhanced(H, syndrome, llr, hard, order, max_combinations) (src/decoding/osd.py:5-77), batched.  The OSD-0 solution is
+ * returned whenever it reproduces the syndrome (osd.py:27-29); otherwise the <= C(order+10, <= order) flip sets over the least
+ * reliable non-pivot positions are scored with recompute_solution / compute_metric (src/decoding/kernels.py:195-219) and the
+ * reference's selection rule.  max_combinations <= 0: no limit (Python None).  order <= 10; at most 65536 flip sets per shot
+ * (QLDPC_ERR_UNSUPPORTED beyond, use max_combinations).  Ties of |llr|: ascending index (see qldpc_osd0_batch). */
+int qldpc_osdw_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *llr, const int8_t *hard,
+                     const int32_t *ordering, int order, int64_t max_combinations, int8_t *solution);
 
 /* a10: generate_noisy_circuit_jit (src/noise/kernels.py:175-353), batched over B draws of explicit random
  * arrays rv/rp/rt [B][n_locs]; out_* [B][cap]; out_len int64[B]. */

@@ -269,6 +269,18 @@ def osd0(indptr, indices, n, syndrome, llr, hard, ordering=None):
     return sol
 
 
+def osdw(indptr, indices, n, syndrome, llr, hard, order, max_combinations=None, ordering=None):
+    """performOSD_enhanced with order >= 0 (osd.py:5-77) -> int8[n]."""
+    indptr, indices = _i32(indptr), _i32(indices)
+    m = indptr.size - 1
+    s, l, h = _i8(syndrome), _f64(llr), _i8(hard)
+    sol = np.zeros(n, np.int8)
+    o = None if ordering is None else _i32(ordering)
+    lib().orc_osdw(C.c_int(m), C.c_int(n), _p(indptr, C.c_int32), _p(indices, C.c_int32), _p(s, C.c_int8), _p(l, C.c_double),
+                   _p(h, C.c_int8), None if o is None else _p(o, C.c_int32), C.c_int(order), C.c_int64(max_combinations or 0), _p(sol, C.c_int8))
+    return sol
+
+
 def prior_llrs(probs):
     probs = _f64(probs)
     out = np.zeros(probs.size)

@@ -495,6 +495,98 @@ ORC_API void orc_osd0(int m, int n, const int32_t *indptr, const int32_t *indice
     free(pr); free(b); free(A); free(inv); free(ordering);
 }
 
+/* f1: performOSD_enhanced with order > 0 (osd.py:5-77), literal.  H as CSR.  `ordering` may be NULL (stable argsort of |llr|);
+ * the second sort (osd.py:37-38, the non-pivot positions by |llr|) is stable with ties by ascending permuted position.
+ * max_combinations <= 0 means "no limit" (Python None / 0).  solution[n]. */
+static double orc_osd_metric(int n, const int8_t *sol, const double *llr_abs, int syndrome_weight) {
+    double metric = (syndrome_weight > 0) ? 1e10 + syndrome_weight * 1e8 : 0.0;          /* kernels.py:197-200 */
+    for (int i = 0; i < n; i++) metric += (double)sol[i] * llr_abs[i];                   /* kernels.py:201-202 */
+    return metric;
+}
+
+ORC_API void orc_osdw(int m, int n, const int32_t *indptr, const int32_t *indices, const int8_t *syndrome, const double *llr,
+                      const int8_t *hard, const int32_t *ordering_in, int order, int64_t max_combinations, int8_t *solution) {
+    const int nw = orc_packed_words(n);
+    int32_t *ordering = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1)), *inv = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    if (ordering_in) memcpy(ordering, ordering_in, sizeof(int32_t) * (size_t)n); else orc_argsort_abs(n, llr, ordering);
+    for (int c = 0; c < n; c++) inv[ordering[c]] = c;
+    double *llr_abs = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    for (int j = 0; j < n; j++) llr_abs[j] = fabs(llr[j]);
+    uint64_t *A = (uint64_t *)calloc((size_t)m * nw + 1, sizeof(uint64_t));
+    uint8_t *b = (uint8_t *)malloc((size_t)m + 1);
+    for (int i = 0; i < m; i++) {
+        int s = 0;
+        for (int e = indptr[i]; e < indptr[i + 1]; e++) { const int j = indices[e]; s ^= hard[j]; const int c = inv[j]; A[(size_t)i * nw + (c >> 6)] |= (uint64_t)1 << (c & 63); }
+        b[i] = (uint8_t)((syndrome[i] + s) & 1);
+    }
+    const int maxp = m < n ? m : n;
+    int64_t *pr = (int64_t *)malloc(sizeof(int64_t) * (size_t)(2 * maxp + 2)), *pc = pr + maxp + 1;
+    const int np_ = orc_gf2_elimination_packed(m, n, nw, A, b, pr, pc);                  /* osd.py:15-17: b is s_reduced now */
+    int8_t *e_perm = (int8_t *)calloc((size_t)n + 1, 1);
+    for (int t = 0; t < np_; t++) e_perm[pc[t]] = (int8_t)b[pr[t]];                      /* osd.py:19-21 */
+    for (int j = 0; j < n; j++) solution[j] = hard[j];
+    for (int c = 0; c < n; c++) { const int j = ordering[c]; solution[j] = (int8_t)((hard[j] + e_perm[c]) & 1); }   /* osd.py:23-25 */
+    int8_t *chk = (int8_t *)malloc((size_t)m + 1);
+    orc_syndrome_check(m, indptr, indices, solution, chk);
+    int w0 = 0;
+    for (int i = 0; i < m; i++) w0 += (chk[i] != (syndrome[i] & 1));
+    if (w0 == 0 || order == 0) goto done;                                                /* osd.py:27-29 */
+    {
+        uint8_t *is_pivot = (uint8_t *)calloc((size_t)n + 1, 1);
+        for (int t = 0; t < np_; t++) is_pivot[pc[t]] = 1;
+        orc_kv *np_list = (orc_kv *)malloc(sizeof(orc_kv) * (size_t)(n + 1));
+        int nn = 0;
+        for (int c = 0; c < n; c++) if (!is_pivot[c]) { double a = llr_abs[ordering[c]]; np_list[nn].key = (a != a) ? INFINITY : a; np_list[nn].idx = c; nn++; }   /* osd.py:31-36 */
+        free(is_pivot);
+        if (nn == 0) { free(np_list); goto done; }
+        qsort(np_list, (size_t)nn, sizeof(orc_kv), orc_kv_cmp);                          /* osd.py:37-38 */
+        const int K = nn < order + 10 ? nn : order + 10;                                 /* osd.py:40-41 */
+        int8_t *best = (int8_t *)malloc((size_t)n + 1), *e_full = (int8_t *)malloc((size_t)n + 1), *test = (int8_t *)malloc((size_t)n + 1);
+        memcpy(best, solution, (size_t)n);
+        double best_metric = orc_osd_metric(n, solution, llr_abs, w0);                   /* osd.py:43-45 */
+        int found_valid = 0;
+        int64_t tested = 0;
+        int comb[64];
+        const int wmax = order < K ? order : K;
+        for (int w = 1; w <= wmax && w < 64; w++) {                                      /* osd.py:48 */
+            if (max_combinations > 0 && tested >= max_combinations) break;
+            for (int t = 0; t < w; t++) comb[t] = t;
+            for (;;) {                                                                   /* itertools.combinations order */
+                if (max_combinations > 0 && tested >= max_combinations) break;
+                memcpy(e_full, e_perm, (size_t)n);
+                for (int t = 0; t < w; t++) e_full[np_list[comb[t]].idx] ^= 1;           /* osd.py:53-54 */
+                for (int t = 0; t < np_; t++) {                                          /* recompute_solution kernels.py:205-219 on the ORIGINAL permuted H */
+                    const int r = (int)pr[t], c = (int)pc[t];
+                    int acc = 0;
+                    for (int e = indptr[r]; e < indptr[r + 1]; e++) { const int col = inv[indices[e]]; if (col != c) acc ^= e_full[col]; }
+                    e_full[c] = (int8_t)(b[r] ^ acc);
+                }
+                for (int c = 0; c < n; c++) { const int j = ordering[c]; test[j] = (int8_t)((hard[j] + e_full[c]) & 1); }   /* osd.py:57-59 */
+                orc_syndrome_check(m, indptr, indices, test, chk);
+                int wt = 0;
+                for (int i = 0; i < m; i++) wt += (chk[i] != (syndrome[i] & 1));
+                if (wt == 0) {                                                           /* osd.py:63-68 */
+                    const double mt = orc_osd_metric(n, test, llr_abs, 0);
+                    if (!found_valid || mt < best_metric) { memcpy(best, test, (size_t)n); best_metric = mt; found_valid = 1; }
+                } else if (!found_valid) {                                               /* osd.py:69-73 */
+                    const double mt = orc_osd_metric(n, test, llr_abs, wt);
+                    if (mt < best_metric) { memcpy(best, test, (size_t)n); best_metric = mt; }
+                }
+                tested++;
+                int t = w - 1;
+                while (t >= 0 && comb[t] == K - w + t) t--;
+                if (t < 0) break;
+                comb[t]++;
+                for (int u = t + 1; u < w; u++) comb[u] = comb[u - 1] + 1;
+            }
+        }
+        memcpy(solution, best, (size_t)n);
+        free(best); free(e_full); free(test); free(np_list);
+    }
+done:
+    free(chk); free(e_perm); free(pr); free(b); free(A); free(llr_abs); free(inv); free(ordering);
+}
+
 /* a15: prior LLRs (src/simulation/engine.py:210-212): clip(nan_to_num(log((1-p)/p)), -50, 50) */
 ORC_API void orc_prior_llrs(int n, const double *probs, double *llr) {
     for (int j = 0; j < n; j++) {

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -232,6 +233,201 @@ int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_
     return QLDPC_OK;
 }
 
+// ------------------------------------------------------------------------------------------ OSD-w (f1)
+// performOSD_enhanced with order > 0 (reference src/decoding/osd.py:5-77).  The reference enters the combination sweep only when
+// the OSD-0 solution misses the syndrome (osd.py:27-29), i.e. for syndromes outside the column space of H -- never for the
+// syndromes the Monte-Carlo engine produces -- so this is a completeness path, written for clarity: one workgroup per shot, the
+// literal elimination above, then one THREAD per candidate flip set (<= C(order+10, <= order) of them).
+constexpr int kOsdwMaxOrder = 10;
+constexpr int kOsdwMaxTest = kOsdwMaxOrder + 10;
+constexpr int kOsdwMaxCand = 1 << 16;
+
+struct OsdwArgs {
+    OsdArgs base;
+    int order;
+    int64_t maxc;                 // <= 0: unlimited
+    uint8_t *isp, *eperm;         // [grid][n]
+    int8_t *efull;                // [grid][block][n]  per-thread candidate in permuted positions
+    double *cmetric;              // [grid][kOsdwMaxCand]
+    int32_t *cweight;             // [grid][kOsdwMaxCand]
+};
+
+__device__ inline unsigned osdw_binom(const unsigned (*bin)[kOsdwMaxOrder + 2], int a, int b) { return (b < 0 || a < b) ? 0u : bin[a][b]; }
+
+// candidate -> flips (w positions into the test list), itertools.combinations order within one weight
+__device__ inline void osdw_unrank(const unsigned (*bin)[kOsdwMaxOrder + 2], int K, int w, unsigned r, int *comb) {
+    int x = 0;
+    for (int t = 0; t < w; t++) {
+        for (;;) {
+            const unsigned c = osdw_binom(bin, K - 1 - x, w - 1 - t);
+            if (c > r) break;
+            r -= c; x++;
+        }
+        comb[t] = x++;
+    }
+}
+
+// recompute_solution (kernels.py:205-219) on the ORIGINAL permuted matrix, then syndrome weight and metric (kernels.py:195-203)
+__device__ inline void osdw_evaluate(const OsdArgs &P, int np, const int32_t *ord, const int32_t *inv, const int32_t *prow, const int32_t *pcol,
+                                     const uint8_t *b, const int8_t *hard, const int8_t *synd, const double *llr, int8_t *e, int &weight,
+                                     double &metric) {
+    for (int t = 0; t < np; t++) {
+        const int r = prow[t], c = pcol[t];
+        int acc = 0;
+        for (int k = P.indptr[r]; k < P.indptr[r + 1]; k++) { const int col = inv[P.indices[k]]; if (col != c) acc ^= e[col]; }
+        e[c] = (int8_t)(b[r] ^ acc);
+    }
+    int wt = 0;
+    for (int i = 0; i < P.m; i++) {
+        int sp = 0;
+        for (int k = P.indptr[i]; k < P.indptr[i + 1]; k++) { const int j = P.indices[k]; sp ^= (hard[j] ^ e[inv[j]]) & 1; }
+        wt += (sp != (synd[i] & 1));
+    }
+    double mt = (wt > 0) ? 1e10 + wt * 1e8 : 0.0;
+    for (int j = 0; j < P.n; j++) mt += (double)((hard[j] ^ e[inv[j]]) & 1) * fabs(llr[j]);
+    weight = wt; metric = mt;
+}
+
+__global__ __launch_bounds__(256) void osdw_kernel(OsdwArgs W) {
+    extern __shared__ unsigned char lds_raw[];
+    __shared__ unsigned s_bin[kOsdwMaxTest + 1][kOsdwMaxOrder + 2];
+    __shared__ int s_tp[kOsdwMaxTest];
+    __shared__ double s_tk[kOsdwMaxTest];
+    __shared__ int s_w0, s_K, s_best;
+    const OsdArgs &P = W.base;
+    const int m = P.m, n = P.n, nwords = P.nwords, tid = threadIdx.x, T = blockDim.x;
+    const int maxp = m < n ? m : n;
+    ElimShared S = carve_elim(lds_raw, m, nwords);
+    uint64_t *A = P.A + (size_t)blockIdx.x * m * nwords;
+    uint8_t *b = P.b + (size_t)blockIdx.x * m;
+    int32_t *ord = P.ord + (size_t)blockIdx.x * n, *inv = P.inv + (size_t)blockIdx.x * n;
+    int32_t *prow = P.prow + (size_t)blockIdx.x * maxp, *pcol = P.pcol + (size_t)blockIdx.x * maxp;
+    double *keys = P.keys + (size_t)blockIdx.x * n;
+    uint8_t *isp = W.isp + (size_t)blockIdx.x * n, *eperm = W.eperm + (size_t)blockIdx.x * n;
+    int8_t *mine = W.efull + ((size_t)blockIdx.x * T + tid) * n;
+    double *cmetric = W.cmetric + (size_t)blockIdx.x * kOsdwMaxCand;
+    int32_t *cweight = W.cweight + (size_t)blockIdx.x * kOsdwMaxCand;
+    if (tid == 0)
+        for (int a = 0; a <= kOsdwMaxTest; a++)
+            for (int c = 0; c <= kOsdwMaxOrder + 1; c++) s_bin[a][c] = (c == 0) ? 1u : (a == 0 ? 0u : s_bin[a - 1][c - 1] + (c <= a - 1 ? s_bin[a - 1][c] : 0u));
+    const int total = *P.count;
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int64_t shot = P.list[item];
+        const double *llr = P.llr + shot * n;
+        const int8_t *hard = P.hard + shot * n, *synd = P.synd + shot * m;
+        int8_t *sol = P.solution + shot * n;
+        if (P.ordering) {
+            for (int c = tid; c < n; c += T) ord[c] = P.ordering[shot * n + c];
+        } else {
+            for (int j = tid; j < n; j += T) { const double a = fabs(llr[j]); keys[j] = (a != a) ? INFINITY : a; }
+            __syncthreads();
+            for (int j = tid; j < n; j += T) {
+                const double kj = keys[j];
+                int rank = 0;
+                for (int i = 0; i < n; i++) { const double ki = keys[i]; rank += (ki < kj || (ki == kj && i < j)) ? 1 : 0; }
+                ord[rank] = j;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += T) { inv[ord[c]] = c; isp[c] = 0; eperm[c] = 0; }
+        for (int64_t t = tid; t < (int64_t)m * nwords; t += T) A[t] = 0;
+        if (tid == 0) { s_w0 = 0; s_best = -1; }
+        __syncthreads();
+        for (int i = tid; i < m; i += T) {
+            int sp = 0;
+            for (int e = P.indptr[i]; e < P.indptr[i + 1]; e++) {
+                const int j = P.indices[e];
+                sp ^= hard[j];
+                const int c = inv[j];
+                A[(size_t)i * nwords + (c >> 6)] |= 1ull << (c & 63);
+            }
+            b[i] = (uint8_t)((synd[i] + sp) & 1);
+        }
+        __syncthreads();
+        const int np = eliminate_packed<int32_t>(A, b, m, n, nwords, prow, pcol, S);      // osd.py:15-17; b = s_reduced from here on
+        __syncthreads();
+        for (int t = tid; t < np; t += T) { eperm[pcol[t]] = b[prow[t]]; isp[pcol[t]] = 1; }   // osd.py:19-21
+        __syncthreads();
+        for (int j = tid; j < n; j += T) sol[j] = (int8_t)((hard[j] + eperm[inv[j]]) & 1);     // osd.py:23-25
+        __syncthreads();
+        for (int i = tid; i < m; i += T) {                                                 // osd.py:27
+            int sp = 0;
+            for (int e = P.indptr[i]; e < P.indptr[i + 1]; e++) sp ^= sol[P.indices[e]] & 1;
+            if (sp != (synd[i] & 1)) atomicAdd(&s_w0, 1);
+        }
+        __syncthreads();
+        const int w0 = s_w0;
+        if (w0 == 0 || W.order == 0) { __syncthreads(); continue; }                        // osd.py:28-29
+        // test positions: the order+10 least reliable non-pivot positions, stable in (|llr|, position) (osd.py:31-41)
+        if (tid == 0) {
+            const int want = W.order + 10;
+            int K = 0;
+            for (int c = 0; c < n; c++) {
+                if (isp[c]) continue;
+                double a = fabs(llr[ord[c]]);
+                if (a != a) a = INFINITY;
+                if (K == want && !(a < s_tk[K - 1])) continue;
+                int at = (K < want) ? K : K - 1;
+                while (at > 0 && a < s_tk[at - 1]) { s_tk[at] = s_tk[at - 1]; s_tp[at] = s_tp[at - 1]; at--; }
+                s_tk[at] = a; s_tp[at] = c;
+                if (K < want) K++;
+            }
+            s_K = K;
+        }
+        __syncthreads();
+        const int K = s_K;
+        if (K == 0) { __syncthreads(); continue; }                                         // osd.py:33-34
+        const int wmax = W.order < K ? W.order : K;
+        long long ncand = 0;
+        for (int w = 1; w <= wmax; w++) ncand += s_bin[K][w];
+        if (W.maxc > 0 && ncand > W.maxc) ncand = W.maxc;                                   // osd.py:49,51
+        if (ncand > kOsdwMaxCand) ncand = kOsdwMaxCand;                                     // host refuses configurations that could exceed this
+        for (int idx = tid; idx < (int)ncand; idx += T) {
+            unsigned r = (unsigned)idx;
+            int w = 1;
+            while (r >= s_bin[K][w]) { r -= s_bin[K][w]; w++; }
+            int comb[kOsdwMaxOrder];
+            osdw_unrank(s_bin, K, w, r, comb);
+            for (int c = 0; c < n; c++) mine[c] = (int8_t)eperm[c];                         // osd.py:53
+            for (int t = 0; t < w; t++) mine[s_tp[comb[t]]] ^= 1;                           // osd.py:54
+            int wt; double mt;
+            osdw_evaluate(P, np, ord, inv, prow, pcol, b, hard, synd, llr, mine, wt, mt);
+            cweight[idx] = wt; cmetric[idx] = mt;
+        }
+        __syncthreads();
+        if (tid == 0) {                                                                     // osd.py:43-46, 63-75 in enumeration order
+            double best_metric = 1e10 + w0 * 1e8;
+            for (int j = 0; j < n; j++) best_metric += (double)(sol[j] & 1) * fabs(llr[j]);
+            bool found_valid = false;
+            int best = -1;
+            for (int idx = 0; idx < (int)ncand; idx++) {
+                const double mt = cmetric[idx];
+                if (cweight[idx] == 0) {
+                    if (!found_valid || mt < best_metric) { best = idx; best_metric = mt; found_valid = true; }
+                } else if (!found_valid && mt < best_metric) { best = idx; best_metric = mt; }
+            }
+            s_best = best;
+            if (best >= 0) {                                                                // rebuild the winner in this thread's slab
+                unsigned r = (unsigned)best;
+                int w = 1;
+                while (r >= s_bin[K][w]) { r -= s_bin[K][w]; w++; }
+                int comb[kOsdwMaxOrder];
+                osdw_unrank(s_bin, K, w, r, comb);
+                for (int c = 0; c < n; c++) mine[c] = (int8_t)eperm[c];
+                for (int t = 0; t < w; t++) mine[s_tp[comb[t]]] ^= 1;
+                int wt; double mt;
+                osdw_evaluate(P, np, ord, inv, prow, pcol, b, hard, synd, llr, mine, wt, mt);
+            }
+        }
+        __syncthreads();
+        if (s_best >= 0) {
+            const int8_t *win = W.efull + (size_t)blockIdx.x * T * n;                      // thread 0's slab
+            for (int j = tid; j < n; j += T) sol[j] = (int8_t)((hard[j] + win[inv[j]]) & 1);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void iota_list_kernel(int64_t B, int32_t *list, int32_t *count) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < B) list[t] = (int32_t)t;
@@ -341,6 +537,65 @@ QLDPC_EXPORT int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t 
     }
     if (rc != QLDPC_OK) return rc;
     QLDPC_HIP_TRY(hipMemcpy(solution, dsol.p, B * n, hipMemcpyDeviceToHost));
+    return QLDPC_OK;
+}
+
+// f1: batched performOSD_enhanced(order, max_combinations) (osd.py:5-77); order == 0 is qldpc_osd0_batch.
+QLDPC_EXPORT int qldpc_osdw_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *llr, const int8_t *hard,
+                                  const int32_t *ordering, int order, int64_t max_combinations, int8_t *solution) {
+    QLDPC_REQUIRE(g != nullptr, "graph is NULL");
+    QLDPC_REQUIRE(order >= 0, "order must be >= 0");
+    if (order == 0) return qldpc_osd0_batch(g, B, syndromes, llr, hard, ordering, solution);
+    QLDPC_REQUIRE(B >= 0 && B < ((int64_t)1 << 31), "batch out of range");
+    QLDPC_REQUIRE(order <= kOsdwMaxOrder, "OSD order %d above the supported maximum %d", order, kOsdwMaxOrder);
+    int rc = use_device(g->device);
+    if (rc != QLDPC_OK) return rc;
+    if (B == 0 || g->n == 0) return QLDPC_OK;
+    QLDPC_REQUIRE(llr && hard && solution && (syndromes || g->m == 0), "NULL buffer");
+    const int m = g->m, n = g->n;
+    if (m == 0) { std::memcpy(solution, hard, (size_t)B * n); return QLDPC_OK; }
+    {   // worst-case number of candidates per shot: sum_{w<=order} C(min(n, order+10), w), cut by max_combinations
+        const int K = std::min(n, order + 10);
+        double worst = 0, c = 1;
+        for (int w = 1; w <= std::min(order, K); w++) { c = c * (K - w + 1) / w; worst += c; }
+        if (max_combinations > 0 && worst > (double)max_combinations) worst = (double)max_combinations;
+        if (worst > kOsdwMaxCand) {
+            set_error("OSD-%d would test up to %.0f flip sets per shot; pass max_combinations <= %d", order, worst, kOsdwMaxCand);
+            return QLDPC_ERR_UNSUPPORTED;
+        }
+    }
+    const int nwords = ((n + 7) / 8 + 7) / 8, maxp = m < n ? m : n, block = 256;
+    const size_t lds = elim_lds_bytes(m, nwords);
+    if (lds > 150 * 1024) { set_error("OSD-w: matrix too large for the LDS scratch (m=%d nwords=%d)", m, nwords); return QLDPC_ERR_UNSUPPORTED; }
+    const size_t slab = (size_t)m * nwords * 8 + (size_t)m + (size_t)n * 18 + (size_t)maxp * 8 + (size_t)block * n + (size_t)kOsdwMaxCand * 12 + 256;
+    int grid = (int)std::min<int64_t>(B, 64);
+    while (grid > 1 && (size_t)grid * slab > ((size_t)2 << 30)) grid /= 2;
+    DevTmp ds, dl, dh, dord, dsol, dlist, dcnt, dA, dkeys, do_, dinv, dpr, dpc, db, disp, dep, def, dcm, dcw;
+    if ((rc = ds.alloc((size_t)B * m)) || (rc = dl.alloc((size_t)B * n * 8)) || (rc = dh.alloc((size_t)B * n)) || (rc = dsol.alloc((size_t)B * n)) ||
+        (rc = dlist.alloc((size_t)B * 4)) || (rc = dcnt.alloc(16)) || (rc = dA.alloc((size_t)grid * m * nwords * 8)) ||
+        (rc = dkeys.alloc((size_t)grid * n * 8)) || (rc = do_.alloc((size_t)grid * n * 4)) || (rc = dinv.alloc((size_t)grid * n * 4)) ||
+        (rc = dpr.alloc((size_t)grid * maxp * 4)) || (rc = dpc.alloc((size_t)grid * maxp * 4)) || (rc = db.alloc((size_t)grid * m)) ||
+        (rc = disp.alloc((size_t)grid * n)) || (rc = dep.alloc((size_t)grid * n)) || (rc = def.alloc((size_t)grid * block * n)) ||
+        (rc = dcm.alloc((size_t)grid * kOsdwMaxCand * 8)) || (rc = dcw.alloc((size_t)grid * kOsdwMaxCand * 4)))
+        return rc;
+    if (ordering && (rc = dord.alloc((size_t)B * n * 4))) return rc;
+    QLDPC_HIP_TRY(hipMemcpy(ds.p, syndromes, (size_t)B * m, hipMemcpyHostToDevice));
+    QLDPC_HIP_TRY(hipMemcpy(dl.p, llr, (size_t)B * n * 8, hipMemcpyHostToDevice));
+    QLDPC_HIP_TRY(hipMemcpy(dh.p, hard, (size_t)B * n, hipMemcpyHostToDevice));
+    if (ordering) QLDPC_HIP_TRY(hipMemcpy(dord.p, ordering, (size_t)B * n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(iota_list_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, nullptr, B, dlist.as<int32_t>(), dcnt.as<int32_t>());
+    OsdwArgs W;
+    W.base.m = m; W.base.n = n; W.base.nwords = nwords; W.base.indptr = g->d_indptr; W.base.indices = g->d_indices;
+    W.base.list = dlist.as<int32_t>(); W.base.count = dcnt.as<int32_t>(); W.base.synd = ds.as<int8_t>(); W.base.llr = dl.as<double>();
+    W.base.hard = dh.as<int8_t>(); W.base.ordering = ordering ? dord.as<int32_t>() : nullptr; W.base.solution = dsol.as<int8_t>();
+    W.base.A = dA.as<uint64_t>(); W.base.b = db.as<uint8_t>(); W.base.ord = do_.as<int32_t>(); W.base.inv = dinv.as<int32_t>();
+    W.base.prow = dpr.as<int32_t>(); W.base.pcol = dpc.as<int32_t>(); W.base.keys = dkeys.as<double>();
+    W.order = order; W.maxc = max_combinations;
+    W.isp = disp.as<uint8_t>(); W.eperm = dep.as<uint8_t>(); W.efull = def.as<int8_t>(); W.cmetric = dcm.as<double>(); W.cweight = dcw.as<int32_t>();
+    hipLaunchKernelGGL(osdw_kernel, dim3(grid), dim3(block), lds, nullptr, W);
+    QLDPC_HIP_TRY(hipGetLastError());
+    QLDPC_HIP_TRY(hipDeviceSynchronize());
+    QLDPC_HIP_TRY(hipMemcpy(solution, dsol.p, (size_t)B * n, hipMemcpyDeviceToHost));
     return QLDPC_OK;
 }
 

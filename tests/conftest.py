@@ -108,3 +108,17 @@ def reference_fit(samples, bits, bins, flip=False):
     fit = popt[0] * x
     tot = np.sum((y - np.mean(y)) ** 2)
     return popt[0], 1.0 - (np.sum((y - fit) ** 2) / tot if tot > 0 else np.nan), h0, h1, edges
+
+
+def osdw_cases(G):
+    """Cases of tests/golden/osdw.npz (reference performOSD_enhanced with order > 0) with their matrices in CSR form."""
+    from scipy.sparse import csr_matrix
+    out = []
+    for name in [str(x) for x in G["cases"]]:
+        H = csr_matrix(G[f"graph__{str(G[f'{name}__graph'])}"].astype(np.int8))
+        H.sort_indices()
+        g = lambda k: G[f"{name}__{k}"]          # noqa: E731
+        out.append(dict(name=name, H=H, indptr=H.indptr.astype(np.int32), indices=H.indices.astype(np.int32), n=H.shape[1], order=int(g("order")),
+                        maxc=int(g("maxc")) or None, syndrome=g("syndrome"), llr=g("llr"), hard=g("hard"), ordering=g("ordering"),
+                        solution=g("solution"), swept=bool(g("swept")), differs=bool(g("differs_from_osd0"))))
+    return out

@@ -507,11 +507,82 @@ def gen_estimators():
     save("estimators", **out)
 
 
+def gen_osdw():
+    """f1: performOSD_enhanced with order > 0 on syndromes OSD-0 cannot satisfy (the only case in which osd.py:31-75 runs)."""
+    rng = np.random.default_rng(606)
+    c = load_code("bb72")
+    mats = {"bb72x": np.asarray(c["Hx"], dtype=np.int64),
+            "dup": np.array([[1, 1, 0, 1, 0, 0, 1], [0, 1, 1, 0, 1, 0, 0], [1, 1, 0, 1, 0, 0, 1], [1, 0, 1, 1, 1, 0, 1], [0, 0, 0, 1, 1, 1, 0]], dtype=np.int64)}
+    out = {}
+    names = []
+    real_argsort = np.argsort
+    for t, (mm, nn, dens) in enumerate(((6, 10, 0.35), (8, 14, 0.3), (5, 9, 0.4), (10, 16, 0.25))):
+        Hs = (rng.random((mm, nn)) < dens).astype(np.int64)
+        Hs[mm // 2] = Hs[0] ^ Hs[1]                   # a dependent row: random syndromes are mostly inconsistent
+        mats[f"rnd{t}"] = Hs
+    plan = [("bb72x", o, mc) for o in (1, 2, 3) for mc in (None, 7)] + [("bb72x", 2, 40), ("dup", 1, None), ("dup", 2, None), ("dup", 3, 4),
+                                                                         ("dup", 5, None), ("bb72x", 2, "consistent")]
+    plan += [(f"rnd{t}", o, mc) for t in range(4) for o, mc in ((1, None), (2, None), (2, 9), (3, None), (4, 25), (2, None), (3, None), (1, None))]
+    for k, (tag, order, mc) in enumerate(plan):
+        H = mats[tag]
+        m, n = H.shape
+        want_change = tag.startswith("rnd") and k % 2 == 0       # half of the small cases must end on a swept candidate
+        for attempt in range(2000):
+            llr = rng.normal(0, 3, n)
+            hard = (rng.random(n) < 0.1).astype(np.int64)
+            if mc == "consistent":
+                synd = (H @ (rng.random(n) < 0.1).astype(np.int64)) % 2
+            else:
+                synd = (rng.random(m) < 0.5).astype(np.int64)
+            seen = []
+
+            def spy(a, *aa, **kk):
+                r = real_argsort(a, *aa, **kk)
+                seen.append(r.copy())
+                return r
+            OSD.np.argsort = spy
+            try:
+                sol = OSD.performOSD_enhanced(H.astype(np.float64), synd, llr, hard, order=order, max_combinations=None if mc == "consistent" else mc)
+                sol0 = OSD.performOSD_enhanced(H.astype(np.float64), synd, llr, hard, order=0)
+            finally:
+                OSD.np.argsort = real_argsort
+            if not want_change or not np.array_equal(np.asarray(sol) % 2, np.asarray(sol0) % 2):
+                break
+        else:
+            raise SystemExit(f"no draw of case {k} changes the answer")
+        if mc == "consistent":
+            mc = None
+        sol = np.asarray(sol, dtype=np.int64) % 2
+        swept = len(seen) >= 3                      # ordering, second sort (only when the sweep runs), ordering of the order-0 call
+        if swept:
+            assert np.array_equal(seen[1], np.arange(len(seen[1]))), "second argsort is not the identity: tie in the fixture"
+        name = f"case{k}"
+        names.append(name)
+        out[f"{name}__graph"] = np.array(tag)
+        out[f"{name}__order"] = np.int64(order)
+        out[f"{name}__maxc"] = np.int64(mc or 0)
+        out[f"{name}__syndrome"] = synd.astype(np.int8)
+        out[f"{name}__llr"] = llr
+        out[f"{name}__hard"] = hard.astype(np.int8)
+        out[f"{name}__ordering"] = seen[0].astype(np.int32)
+        out[f"{name}__solution"] = sol.astype(np.int8)
+        out[f"{name}__swept"] = np.int64(swept)
+        out[f"{name}__differs_from_osd0"] = np.int64(not np.array_equal(sol, np.asarray(sol0) % 2))
+        print(f"    {name}: {tag} order={order} maxc={mc} swept={swept} differs={out[f'{name}__differs_from_osd0']}")
+    for tag, H in mats.items():
+        out[f"graph__{tag}"] = H.astype(np.int8)
+    ndiff = sum(int(out[f"{nm}__differs_from_osd0"]) for nm in names)
+    print(f"    {ndiff} of {len(names)} cases end on a swept candidate instead of the OSD-0 solution")
+    assert ndiff >= 6
+    out["cases"] = np.array(names)
+    save("osdw", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["data", "steane", "bb", "core", "gf2", "circ72", "circ144", "estimators"]
+    todo = a.only.split(",") if a.only else ["data", "steane", "bb", "core", "gf2", "circ72", "circ144", "estimators", "osdw"]
     t0 = time.time()
     if "data" in todo:
         print("[data]"); pack_data()
@@ -531,6 +602,8 @@ def main():
         print("[circ144]"); nz = gen_noise("circ144", 4); gen_circuit_decode("circ144", nz, 2, 1, 50)
     if "estimators" in todo:
         print("[estimators]"); gen_estimators()
+    if "osdw" in todo:
+        print("[osdw]"); gen_osdw()
     print(f"done in {time.time() - t0:.0f}s")
 
 

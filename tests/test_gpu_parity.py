@@ -342,6 +342,22 @@ def test_circuit_level_tally_matches_oracle(L, oracle, golden, tag, ntrial):
     plan.close()
 
 
+def _two_alpha_tally(oracle, circ, secs, seed, count, max_iter, mode, alpha_z, alpha_x):
+    """Oracle tally when the two sectors use different normalisation factors (the oracle entry point takes one): per-trial runs with
+    each factor, Z slots from the first, X slots from the second, total = trials where either sector fails."""
+    A = np.stack([oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], 0.005, seed, i, 1, max_iter=max_iter, alpha=alpha_z, alpha_mode=mode, threads=1)
+                  for i in range(count)])
+    B = np.stack([oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], 0.005, seed, i, 1, max_iter=max_iter, alpha=alpha_x, alpha_mode=mode, threads=1)
+                  for i in range(count)])
+    t = np.zeros(16, np.int64)
+    t[0] = count
+    for zslot in (1, 4, 6, 8, 10, 12):
+        t[zslot] = A[:, zslot].sum()
+        t[zslot + 1] = B[:, zslot + 1].sum()
+    t[3] = int(np.count_nonzero((A[:, 1] != 0) | (B[:, 2] != 0)))
+    return t
+
+
 def test_run_simulation_mirror(L, oracle, golden):
     """run_simulation (engine.py:193-488) on [[72,12,6]] x 6 cycles against the oracle tally for the same trial stream."""
     from qldpc_amd.data import load_code, load_precomputed_matrices
@@ -362,8 +378,22 @@ def test_run_simulation_mirror(L, oracle, golden):
     res3 = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=150, num_cycles=6, maxIter=50, osd_order=2,
                           precomputed_matrices=load_precomputed_matrices("circ72"), base_seed=31337, batch=64, **bb)
     assert np.array_equal(res3["tally"], ref)
-    with pytest.raises(NotImplementedError):
-        run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=10, num_cycles=6, scopt=True, **bb)
+    # estimated normalisation factors (the mode main.py:48 selects) + SCOPT beta: the estimators draw from default_rng(base_seed), Z first
+    from qldpc_amd.decoding.alpha import estimate_alpha_alvarado
+    from qldpc_amd.decoding.scopt import estimate_scopt_beta
+    res4 = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=100, num_cycles=6, maxIter=50, alpha_mode="alvarado", scopt=True,
+                          alpha_estimation_trials=300, precomputed_matrices=load_precomputed_matrices("circ72"), base_seed=4242, batch=64, **bb)
+    rng = np.random.default_rng(4242)
+    az, r2z = estimate_alpha_alvarado(graphs[0], 0.005, trials=300, rng=rng, llrs=priors[0])
+    ax, r2x = estimate_alpha_alvarado(graphs[1], 0.005, trials=300, rng=rng, llrs=priors[1])
+    assert res4["alpha_r2_z"] == r2z and res4["alpha_r2_x"] == r2x and 0 < az < 1.5 and 0 < ax < 1.5
+    bz, _ = estimate_scopt_beta(graphs[0], 0.005, trials=500, alpha=az, alpha_mode="alvarado", maxIter=50, rng=rng, llrs=priors[0])
+    assert res4["beta_z"] == bz and set(["beta_x", "beta_r2_z", "beta_r2_x"]) <= set(res4)
+    assert np.array_equal(res4["tally"], _two_alpha_tally(oracle, circ, secs, 4242, 100, 50, "alvarado", az, ax))
+    res5 = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=60, num_cycles=6, maxIter=4, alpha_mode="alvarado-autoregressive",
+                          alpha_estimation_trials=100, precomputed_matrices=load_precomputed_matrices("circ72"), base_seed=99, batch=64, **bb)
+    assert res5["alpha_values_z"].shape == (4,) and res5["alpha_r2_values_x"].shape == (4,) and res5["num_trials"] == 60
+    assert np.array_equal(res5["tally"], _two_alpha_tally(oracle, circ, secs, 99, 60, 4, "alvarado-autoregressive", res5["alpha_values_z"], res5["alpha_values_x"]))
     # in-order early stop (engine.py:441-464): the run ends AT the trial that brings the error count to the target
     per_trial = np.stack([oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], 0.005, 31337, i, 1, max_iter=50, threads=1) for i in range(150)])
     bad = np.flatnonzero(per_trial[:, 3])
@@ -542,3 +572,44 @@ def test_estimator_statistics_vs_oracle(L, oracle):
     with pytest.raises(ValueError):
         from qldpc_amd.decoding.alpha import estimate_alpha_alvarado
         estimate_alpha_alvarado(np.eye(3, dtype=np.int8), 0.7, llrs=np.ones(3))
+
+
+def test_osd_order_w_golden(L, golden, oracle):
+    """f1: performOSD_enhanced with order > 0 on the GPU against the solutions the REFERENCE returned (tests/golden/osdw.npz: syndromes
+    OSD-0 cannot satisfy, so the flip-set sweep of osd.py:31-75 runs; 18 cases end on a swept candidate), then a batch against the oracle."""
+    from conftest import osdw_cases
+    from qldpc_amd.decoding.osd import performOSD_enhanced
+    cases = osdw_cases(golden("osdw"))
+    for c in cases:
+        Hd = np.asarray(c["H"].todense(), dtype=np.float64)
+        for ordering in (c["ordering"], None):
+            sol = performOSD_enhanced(Hd, c["syndrome"], c["llr"], c["hard"], order=c["order"], max_combinations=c["maxc"], ordering=ordering)
+            assert sol.dtype == np.int64 and np.array_equal(sol, c["solution"]), (c["name"], c["order"], c["maxc"])
+    assert np.array_equal(performOSD_enhanced(Hd, c["syndrome"], c["llr"], c["hard"], order=-3), performOSD_enhanced(Hd, c["syndrome"], c["llr"], c["hard"]))
+    # batch entry point vs the oracle: [[72,12,6]] Hx (rank 30 of 36 rows) with random syndromes, and a wide random matrix
+    import ctypes as C
+    rng = np.random.default_rng(2)
+    from qldpc_amd.data import load_code
+    code = load_code("bb72")
+    wide = (rng.random((7, 11)) < 0.35).astype(np.int8); wide[3] = wide[1] ^ wide[2]; wide[6] = wide[0]
+    total_changed = 0
+    for ip, ix, n in ((code["Hx_indptr"], code["Hx_indices"], 72), L.canonical_csr(wide)[:2] + (11,)):
+        g = L.graph_for(ip, ix, n)
+        B, m = 48, len(ip) - 1
+        synd = (rng.random((B, m)) < 0.5).astype(np.int8)
+        synd[::7] = 0
+        llr = rng.normal(0, 2.5, (B, n)); llr[3, :5] = 0.0; llr[4, 10] = np.inf
+        hard = (rng.random((B, n)) < 0.15).astype(np.int8)
+        for order, maxc in ((1, 0), (2, 0), (3, 50), (4, 0)):
+            sol = np.zeros((B, n), np.int8)
+            L.check(L.lib().qldpc_osdw_batch(g.handle, C.c_int64(B), L.ptr(synd, C.c_int8), L.ptr(llr, C.c_double), L.ptr(hard, C.c_int8), None,
+                                             C.c_int(order), C.c_int64(maxc), L.ptr(sol, C.c_int8)))
+            changed = 0
+            for b in range(B):
+                want = oracle.osdw(ip, ix, n, synd[b], llr[b], hard[b], order, maxc or None)
+                assert np.array_equal(sol[b], want), (n, order, maxc, b)
+                changed += not np.array_equal(want, oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]))
+            total_changed += changed
+    assert total_changed > 0                    # the sweep really replaced OSD-0 answers in the batch
+    with pytest.raises(L.QldpcError):           # 106,761 flip sets per shot: refused without max_combinations
+        performOSD_enhanced(np.asarray(code["Hx"], dtype=np.float64), np.ones(36, np.int8), rng.normal(0, 1, 72), np.zeros(72, np.int8), order=8)

@@ -230,3 +230,16 @@ def test_estimator_trial_loops(oracle, golden):
             assert np.array_equal(h0, c["hist"][0]) and np.array_equal(h1, c["hist"][1]) and np.array_equal(edges, c["edges"][0]), c["name"]
             assert abs(b - c["out"]["beta"]) <= 1e-9 and abs(r2 - c["out"]["r2"]) <= 1e-9
     assert seen == {"alvarado", "autoregressive", "scopt"}
+
+
+def test_osd_order_w_sweep(oracle, golden):
+    """f1: performOSD_enhanced with order > 0 (osd.py:31-75: the combination sweep that runs when OSD-0 misses the syndrome)."""
+    from conftest import osdw_cases
+    cases = osdw_cases(golden("osdw"))
+    for c in cases:
+        for ordering in (c["ordering"], None):          # the fixtures have no |llr| ties, so the default order must agree too
+            sol = oracle.osdw(c["indptr"], c["indices"], c["n"], c["syndrome"], c["llr"], c["hard"], c["order"], c["maxc"], ordering=ordering)
+            assert np.array_equal(sol, c["solution"]), (c["name"], c["order"], c["maxc"])
+        if not c["differs"]:
+            assert np.array_equal(oracle.osd0(c["indptr"], c["indices"], c["n"], c["syndrome"], c["llr"], c["hard"]), c["solution"])
+    assert sum(c["differs"] for c in cases) >= 10 and any(not c["swept"] for c in cases) and any(c["maxc"] for c in cases)
