@@ -74,7 +74,7 @@ struct qldpc_graph {
     int32_t *d_indptr = nullptr, *d_indices = nullptr, *d_colptr = nullptr, *d_rowidx = nullptr, *d_csc2csr = nullptr,
             *d_csr2csc = nullptr;
     // ELL (slot-major) views for the workgroup-per-shot kernel: coalesced index loads across rows / columns
-    uint16_t *d_ell_col = nullptr;   // [max_row_deg][m]  column of the k-th edge of row i, 0xFFFF = none
+    uint16_t *d_ell_col = nullptr;   // [round_up(max_row_deg, 8)][m]  column of the k-th edge of row i; unused slots hold column 0
     uint32_t *d_ell_var = nullptr;   // [max_col_deg][n]  (row << 8) | position-in-row of the d-th edge of column j (ascending rows)
     // workspace cache for the decode kernels (guarded by mu; one decode at a time per graph handle)
     mutable std::mutex mu;

@@ -637,7 +637,7 @@ struct OsdLdsArgs {
 #define QLDPC_OSD_BLOCK 16
 #endif
 constexpr int kOsdBlock = QLDPC_OSD_BLOCK;      // columns resolved per block (4 per register of the resolving wave)
-constexpr int kOsdRegs = kOsdBlock / 4;
+static_assert(kOsdBlock <= 16, "one wave per column, at most 4 columns per wave with 256-thread blocks");
 __device__ __forceinline__ unsigned long long r_mask_word(const unsigned long long *R, int t, int mw, int w) { return R[t * mw + w]; }
 
 __device__ __forceinline__ unsigned long long osd_key(double x) {
@@ -665,6 +665,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     unsigned long long *R = reinterpret_cast<unsigned long long *>(lds + P.offR);       // [kOsdBlock][mw] reduced columns -> masks
     int *blk = reinterpret_cast<int *>(lds + P.offBlk);                    // [0] nb, [1] nops, [2] anydep, [3] next c; [4..] cols[32], opa[32], opp[32], opt[32]
     int *bcol = blk + 4, *opa = bcol + kOsdBlock, *opp = opa + kOsdBlock, *opt = opp + kOsdBlock;
+    int2 *stp = reinterpret_cast<int2 *>(opt + kOsdBlock);      // (a or -1, pp) published by the owner of column t
     uint16_t *ordw = P.ordws + (size_t)blockIdx.x * n;
     const int brow = m + 1;                                                // U row that carries b
 
@@ -763,60 +764,64 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 }
                 __syncthreads();
                 c_p1 += clock64() - tp; tp = clock64();
-                // ---- phase 2: one wave resolves the pivots of the block on the local matrix ----
-                if (tid < 64) {
-                    // local matrix in registers: lane = (grp, w); register j holds word w of column 4*j + grp
-                    const int lane = tid, w = lane & 15, grp = lane >> 4;
-                    unsigned long long X[kOsdRegs];
-#pragma unroll
-                    for (int j = 0; j < kOsdRegs; j++) { const int sc = 4 * j + grp; X[j] = (sc < nb && w < mw) ? R[sc * mw + w] : 0ull; }
-                    int lrow = row, nops = 0, anydep = 0;
+                // ---- phase 2: the block's pivots.  Waves 0-3 (one per SIMD) hold 4 columns each: lane = (grp, w) has word w of column
+                // 4*wave + grp.  Column t's owner finds its pivot (first set bit at a position >= lrow, kernels.py:71-75), turns the
+                // column into the elimination mask and publishes (a, pp); after ONE barrier the waves holding later columns apply that
+                // swap + XOR (kernels.py:79-92 restricted to the block).  Measured alternatives: all 16 columns in a single wave
+                // (1.7 M cycles per shot), one wave per column (1.85 M), four columns resolved inside a wave per barrier (1.75 M);
+                // this form: 1.36 M -- the cost is the dependent ballot -> scalar -> lane-read chain of a step, not the barrier.
+                int nops = 0, anydep = 0;
+                {
+                    const int wv = tid >> 6, lane = tid & 63, w = lane & 15, grp = lane >> 4, sc = 4 * wv + grp;
+                    const bool holder = wv < 4;
+                    unsigned long long X = (holder && sc < nb && w < mw) ? R[sc * mw + w] : 0ull;
+                    const int colid = (holder && sc < nb) ? (int)sidx[bcol[sc]] : 0;
+                    int lrow = row;
                     for (int t = 0; t < nb; t++) {
-                        const int jt = t >> 2, gt = t & 3;
-                        unsigned long long mine = 0ull;
-#pragma unroll
-                        for (int j = 0; j < kOsdRegs; j++) if (j == jt) mine = X[j];                  // uniform select of register jt
-                        const unsigned long long rp = __shfl(mine, gt * 16 + w);                      // word w of the pivot column, in every group
-                        const int wq = lrow >> 6;
-                        const unsigned long long mword = (w < wq) ? 0ull : ((w == wq) ? (rp & (~0ull << (lrow & 63))) : rp);
-                        const unsigned long long bal = __ballot(mword != 0ull && grp == 0) & 0xFFFFull;
-                        if (bal == 0ull) { anydep = 1; if (lane == 0) alive[bcol[t]] = 0; continue; }  // dependent on the pivots so far
-                        const int pw = __builtin_ctzll(bal);
-                        const unsigned long long pword = __shfl(mword, pw);
-                        const int pp = pw * 64 + __builtin_ctzll(pword);                               // first candidate position (kernels.py:71-75)
-                        const int a = lrow, wa = a >> 6, wp = pp >> 6;
-                        const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
-                        // swap bits a <-> pp of the pivot column itself (bit pp is 1), then clear bit a: that is the elimination mask
-                        const bool la = (w == wa), lp = (w == wp);
-                        const bool olda = __ballot(grp == 0 && la && (rp & abit) != 0ull) != 0ull;
-                        unsigned long long rm = rp;
-                        if (w == wp) rm = olda ? (rm | pbit) : (rm & ~pbit);
-                        if (w == wa) rm &= ~abit;
-                        // later columns of the block: same swap, then add the mask where the pivot bit is set (kernels.py:88-92)
-#pragma unroll
-                        for (int j = 0; j < kOsdRegs; j++) {
-                            if (4 * j + 3 < t) continue;                                              // (uniform) all four columns of this register are done
-                            const int sc = 4 * j + grp;
-                            unsigned long long x = X[j];
-                            // bits a / pp of the column live in the lanes holding words wa / wp of this group: two ballots instead of shuffles
-                            const unsigned long long balA = __ballot(la && (x & abit) != 0ull), balP = __ballot(lp && (x & pbit) != 0ull);
-                            const bool ba = (balA >> (grp * 16 + wa)) & 1ull, bp = (balP >> (grp * 16 + wp)) & 1ull;
-                            if (ba != bp) { if (la) x ^= abit; if (lp) x ^= pbit; }
-                            if (bp) x ^= rm;                                                          // after the swap, bit a of the column is bp
-                            if (sc == t) x = rm;                                                      // the pivot column's slot keeps the mask
-                            if (sc >= t && sc < nb) X[j] = x;
+                        const int gt = t & 3;
+                        if (wv == (t >> 2)) {
+                            const bool ing = (grp == gt);
+                            const int wq = lrow >> 6;
+                            const unsigned long long mword = (!ing || w < wq) ? 0ull : ((w == wq) ? (X & (~0ull << (lrow & 63))) : X);
+                            const unsigned long long bal = (__ballot(mword != 0ull) >> (gt * 16)) & 0xFFFFull;
+                            if (bal == 0ull) {                                                   // dependent on the pivots so far
+                                if (lane == gt * 16) { stp[t] = make_int2(-1, 0); alive[bcol[t]] = 0; }
+                            } else {
+                                const int pw = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal)), src = gt * 16 + pw;
+                                const unsigned long long pword = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mword >> 32), src) << 32) |
+                                                                 (unsigned)__builtin_amdgcn_readlane((int)mword, src);
+                                const int pp = pw * 64 + __builtin_ctzll(pword), a = lrow, wa = a >> 6, wp = pp >> 6;
+                                const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
+                                const bool olda = __ballot(ing && w == wa && (X & abit) != 0ull) != 0ull;
+                                // swap bits a <-> pp of the pivot column itself (bit pp is 1), then clear bit a: that is the elimination mask
+                                unsigned long long rm = X;
+                                if (w == wp) rm = olda ? (rm | pbit) : (rm & ~pbit);
+                                if (w == wa) rm &= ~abit;
+                                if (ing) { X = rm; if (w < mw) R[t * mw + w] = rm; }
+                                if (lane == gt * 16) { stp[t] = make_int2(a, pp); opa[nops] = a; opp[nops] = pp; opt[nops] = t; pvcol[a] = (uint16_t)colid; }
+                            }
                         }
-                        if (lane == 0) { opa[nops] = a; opp[nops] = pp; opt[nops] = t; pvcol[a] = sidx[bcol[t]]; }
+                        __syncthreads();
+                        const int2 st = stp[t];                                                  // both loads issue together: one LDS round trip
+                        const unsigned long long rmw = (holder && w < mw) ? R[t * mw + w] : 0ull;
+                        if (st.x < 0) { anydep = 1; continue; }
+                        if (holder && 4 * wv + 3 > t) {                                          // wave-uniform: this wave still holds a later column
+                            const int a = st.x, pp = st.y, wa = a >> 6, wp = pp >> 6;
+                            const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
+                            unsigned long long x = X;
+                            // bits a / pp of a column live in the lanes holding words wa / wp of its group: two ballots instead of shuffles
+                            const unsigned long long balA = __ballot(w == wa && (x & abit) != 0ull), balP = __ballot(w == wp && (x & pbit) != 0ull);
+                            const bool ba = (balA >> (grp * 16 + wa)) & 1ull, bp = (balP >> (grp * 16 + wp)) & 1ull;
+                            if (ba != bp) { if (w == wa) x ^= abit; if (w == wp) x ^= pbit; }
+                            if (bp) x ^= rmw;                                                    // after the swap, bit a of the column is bp
+                            if (sc > t && sc < nb) X = x;
+                        }
                         nops++; lrow++;
-                        if (lrow >= P.rankH || lrow >= m) break;                                       // full rank: the remaining columns cannot pivot
+                        if (lrow >= P.rankH || lrow >= m) break;                                 // full rank: the remaining columns cannot pivot
                     }
-#pragma unroll
-                    for (int j = 0; j < kOsdRegs; j++) { const int sc = 4 * j + grp; if (sc < nb && w < mw) R[sc * mw + w] = X[j]; }
-                    if (lane == 0) { blk[1] = nops; blk[2] = anydep; }
                 }
                 __syncthreads();
                 c_p2 += clock64() - tp; tp = clock64();
-                const int nops = blk[1], anydep = blk[2];
                 // ---- phase 3: apply the block's operations to every row of U (and to b) ----
                 for (int q = tid; q < m + 2; q += T) {
                     if (q == m) continue;
@@ -914,7 +919,7 @@ static bool plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
     P.offRows = (int)off; off += (size_t)P.K * P.cdeg * 2;
     P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
     P.offR = (int)off; off += (size_t)kOsdBlock * P.mw * 8;
-    P.offBlk = (int)off; off += (4 + 4 * kOsdBlock) * 4;
+    P.offBlk = (int)off; off += (4 + 6 * kOsdBlock) * 4;
     P.offMisc = (int)off; off += 64;
     lds = off + 16;
     return lds <= 160 * 1024;

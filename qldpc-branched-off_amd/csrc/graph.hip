@@ -123,7 +123,7 @@ QLDPC_EXPORT int qldpc_graph_create(int m, int n, const int32_t *indptr, const i
     if (rc == QLDPC_OK) rc = upload(&g->d_csc2csr, g->csc2csr);
     if (rc == QLDPC_OK) rc = upload(&g->d_csr2csc, g->csr2csc);
     if (rc == QLDPC_OK && n < 65535 && m < (1 << 24) && g->max_row_deg < 256) {
-        std::vector<uint16_t> ec((size_t)std::max(g->max_row_deg, 1) * std::max(m, 1), 0xFFFF);
+        std::vector<uint16_t> ec((size_t)round_up(std::max(g->max_row_deg, 1), 8) * std::max(m, 1), 0);   // slots padded to 8 rows, column 0
         std::vector<uint32_t> ev((size_t)std::max(g->max_col_deg, 1) * std::max(n, 1), 0xFFFFFFFFu);
         for (int i = 0; i < m; i++)
             for (int e = indptr[i]; e < indptr[i + 1]; e++) ec[(size_t)(e - indptr[i]) * m + i] = (uint16_t)indices[e];

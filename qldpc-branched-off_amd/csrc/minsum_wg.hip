@@ -138,55 +138,84 @@ __device__ __forceinline__ double wmin_abs2(double a, double b) { double r; asm(
 __device__ __forceinline__ double wmax_abs2(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double flip_sign(double x, uint32_t signword) { return __hiloint2double(__double2hiint(x) ^ (int)signword, __double2loint(x)); }
 
+// One row of the check pass, edges taken 8 at a time: the 8 index loads (slot-major table, coalesced), then the 8 posterior
+// gathers from LDS are issued back to back before the dependent min/sign chain starts, so their latencies overlap instead
+// of adding up per edge (the per-edge loop the compiler emits otherwise waits for memory twice per edge).
+template <bool NANSEL, bool FIRST>
+__device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int m, const double *__restrict__ V, int deg, double p1s, double p2s,
+                                            uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, bool &par, double &min1,
+                                            double &min2, int &arg, uint32_t &nlo, uint32_t &nhi) {
+    for (int k0 = 0; k0 < deg; k0 += 8) {
+        uint32_t c[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) c[u] = ec[(size_t)(k0 + u) * m];                        // table rows are padded to a multiple of 8 with column 0
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = V[c[u]];
+        const uint32_t pw = (k0 < 32) ? (ip_lo >> k0) : (ip_hi >> (k0 - 32));                // previous sign bits of this chunk
+        const int au = argp - k0;
+        uint32_t cb = 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (k0 + u < deg) {
+                par ^= (v[u] < 0.0);                                                         // kernels.py:349,356
+                double x = v[u];
+                if (!FIRST) {
+                    const double mag = (u == au) ? p2s : p1s;                                // kernels.py:313 (already carries the row sign)
+                    const double r = flip_sign(mag, (pw >> u) << 31);                        // R_{it-1}[e], kernels.py:311-314
+                    x = v[u] - r;                                                            // kernels.py:325
+                    if (NANSEL) x = (x != x) ? 0.0 : x;                                      // kernels.py:328-329
+                    x = wmax(wmin(x, clip), nclip);                                          // kernels.py:330-333
+                }
+                cb |= ((uint32_t)__double2hiint(x) >> 31) << u;                              // x is never -0.0 or NaN here (see above)
+                if (fabs(x) < min1) arg = k0 + u;                                            // kernels.py:301-304 (strict: first minimum wins)
+                min2 = wmin(min2, wmax_abs2(min1, x));                                       // kernels.py:302,305-306
+                min1 = wmin_abs2(min1, x);
+            }
+        }
+        if (k0 < 32) nlo |= cb << k0; else nhi |= cb << (k0 - 32);
+    }
+}
+
 template <bool NANSEL>
 __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     extern __shared__ unsigned char lds[];
     double *V = reinterpret_cast<double *>(lds);
-    double2 *SP = reinterpret_cast<double2 *>(lds + A.offP);        // (alpha*min1, alpha*min2), both already multiplied by the row's total sign
-    uint2 *SI = reinterpret_cast<uint2 *>(lds + A.offI);            // .x = sign bits 0-31, .y = sign bits 32-55 | argmin << 24
+    double2 *SP = reinterpret_cast<double2 *>(lds + A.offP);        // (alpha*min1, alpha*min2), both already multiplied by the row's total sign; [m + 1]
+    uint2 *SI = reinterpret_cast<uint2 *>(lds + A.offI);            // .x = sign bits 0-31, .y = sign bits 32-55 | argmin << 24; [m + 1]
     int *unsat = reinterpret_cast<int *>(lds + A.offF);
     const int m = A.m, n = A.n, max_iter = A.max_iter, tid = threadIdx.x, T = blockDim.x;
     const double clip = A.clip, nclip = -A.clip;
+    const int deg_own = (tid < m) ? A.indptr[tid + 1] - A.indptr[tid] : 0;                   // the thread's first row, constant over shots
+    if (tid == 0) { SP[m] = make_double2(0.0, 0.0); SI[m] = make_uint2(0u, 0u); }            // dummy check read by padded column slots
 
     for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
         for (int j = tid; j < n; j += T) V[j] = A.prior[j];                                  // Q_{-1} = prior[col] (kernels.py:263-265)
         if (tid < 2) unsat[tid] = 0;
+        const bool csyn_own = (tid < m) ? (A.synd[b * m + tid] & 1) : false;
         bool done = false;
         __syncthreads();
         for (int it = 0; it <= max_iter; it++) {
             if (A.fixed || !done) {
                 const double alpha = (it < max_iter) ? A.alpha[it] : 0.0;
                 for (int i = tid; i < m; i += T) {
-                    const int deg = A.indptr[i + 1] - A.indptr[i];
-                    const bool csyn = A.synd[b * m + i] & 1;
-                    double p1s = 0.0, p2s = 0.0;
-                    unsigned long long ip = 0ull;
-                    int argp = 127;
-                    if (it > 0 && deg > 0) {
-                        const double2 t = SP[i]; const uint2 u = SI[i];
-                        p1s = t.x; p2s = t.y; argp = (int)(u.y >> 24); ip = ((unsigned long long)(u.y & 0x00FFFFFFu) << 32) | u.x;
-                    }
+                    const int deg = (i == tid) ? deg_own : A.indptr[i + 1] - A.indptr[i];
+                    const bool csyn = (i == tid) ? csyn_own : (bool)(A.synd[b * m + i] & 1);
                     bool par = csyn;
                     double min1 = INFINITY, min2 = INFINITY;
                     int arg = 127;
                     uint32_t nlo = 0u, nhi = 0u;
-                    for (int k = 0; k < deg; k++) {
-                        const int col = A.ell_col[(size_t)k * m + i];
-                        const double v = V[col];
-                        par ^= (v < 0.0);                                                    // kernels.py:349,356
-                        double x = v;
-                        if (it > 0) {
-                            const double mag = (k == argp) ? p2s : p1s;                      // kernels.py:313 (already carries the row sign)
-                            const double r = flip_sign(mag, (uint32_t)(ip >> k) << 31);      // R_{it-1}[e], kernels.py:311-314
-                            x = v - r;                                                       // kernels.py:325
-                            if (NANSEL) x = (x != x) ? 0.0 : x;                              // kernels.py:328-329
-                            x = wmax(wmin(x, clip), nclip);                                  // kernels.py:330-333
+                    if (it == 0) {
+                        wg_lean_row<NANSEL, true>(A.ell_col + i, m, V, deg, 0.0, 0.0, 0u, 0u, 127, clip, nclip, par, min1, min2, arg, nlo, nhi);
+                    } else {
+                        double p1s = 0.0, p2s = 0.0;
+                        uint32_t ip_lo = 0u, ip_hi = 0u;
+                        int argp = 127;
+                        if (deg > 0) {
+                            const double2 t = SP[i]; const uint2 u = SI[i];
+                            p1s = t.x; p2s = t.y; argp = (int)(u.y >> 24); ip_lo = u.x; ip_hi = u.y & 0x00FFFFFFu;
                         }
-                        const uint32_t sgn = (uint32_t)__double2hiint(x) >> 31;              // x is never -0.0 or NaN here (see above)
-                        if (k < 32) nlo |= sgn << k; else nhi |= sgn << (k - 32);
-                        if (fabs(x) < min1) arg = k;                                         // kernels.py:301-304 (strict: first minimum wins)
-                        min2 = wmin(min2, wmax_abs2(min1, x));                               // kernels.py:302,305-306
-                        min1 = wmin_abs2(min1, x);
+                        wg_lean_row<NANSEL, false>(A.ell_col + i, m, V, deg, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, par, min1, min2, arg, nlo, nhi);
                     }
                     if (it >= 1 && !done && par) unsat[it & 1] = 1;                          // kernels.py:357-359
                     if (it < max_iter && deg > 0) {                                          // kernels.py:285-286
@@ -212,19 +241,32 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
             if (done && !A.fixed) break;
             if (it == max_iter) break;
             if (tid == 0) unsat[(it + 1) & 1] = 0;
-            for (int j = tid; j < n; j += T) {                                               // variable pass: values_it
+            // variable pass: values_it.  Same batching: the column's edge slots are loaded 4 at a time, then the 4 check states.
+            for (int j = tid; j < n; j += T) {
+                const double pr = A.prior[j];
                 double s = 0.0;                                                              // kernels.py:279
-                for (int d = 0; d < A.cdeg; d++) {
-                    const uint32_t e = A.ell_var[(size_t)d * n + j];
-                    if (e == 0xFFFFFFFFu) break;
-                    const int i = (int)(e >> 8), k = (int)(e & 255u);
-                    const double2 pp = SP[i];
-                    const uint2 u = SI[i];
-                    const double mag = (k == (int)(u.y >> 24)) ? pp.y : pp.x;
-                    const unsigned long long bits = ((unsigned long long)u.y << 32) | u.x;
-                    s += flip_sign(mag, (uint32_t)(bits >> k) << 31);                        // kernels.py:316, ascending check order
+                for (int d0 = 0; d0 < A.cdeg; d0 += 4) {
+                    uint32_t e[4];
+                    double2 pp[4];
+                    uint2 si[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) e[u] = (d0 + u < A.cdeg) ? A.ell_var[(size_t)(d0 + u) * n + j] : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t i = min(e[u] >> 8, (uint32_t)m);                      // empty slot -> the dummy check
+                        pp[u] = SP[i]; si[u] = SI[i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (e[u] != 0xFFFFFFFFu) {
+                            const uint32_t k = e[u] & 255u;
+                            const double mag = (k == (si[u].y >> 24)) ? pp[u].y : pp[u].x;
+                            const uint32_t w = (k < 32u) ? (si[u].x >> k) : (si[u].y >> (k - 32u));
+                            s += flip_sign(mag, w << 31);                                    // kernels.py:316, ascending check order
+                        }
+                    }
                 }
-                V[j] = s + A.prior[j];                                                       // kernels.py:320
+                V[j] = s + pr;                                                               // kernels.py:320
             }
             __syncthreads();
         }
@@ -234,8 +276,8 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
 
 static size_t wg_lds_bytes(const qldpc_graph *g, int &offP, int &offI, int &offF) {
     offP = (int)round_up((int64_t)g->n * 8, 16);
-    offI = offP + g->m * 16;
-    offF = offI + g->m * 8;
+    offI = offP + (g->m + 1) * 16;     // one spare check state: the target of empty column slots in the lean kernel
+    offF = offI + (g->m + 1) * 8;
     return (size_t)offF + 16;
 }
 
