@@ -678,20 +678,36 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         const long long t_start = clock64();
         // ---- column order: ascending |llr| (osd.py:11-12), ties by ascending index; bitonic sort of (key, index) in LDS ----
         if (!P.ordering) {
+            // (key, index) pairs sorted IN PLACE (regular, conflict-free addresses; four independent compare-exchanges per thread in
+            // flight).  Network: bitonic merges that are ascending everywhere (first step of a merge pairs i with its mirror
+            // i ^ (size-1)), so the virtual +inf padding at positions >= n never moves and needs no storage.
             unsigned long long *keys = reinterpret_cast<unsigned long long *>(lds);                 // [n]   (aliases U)
-            uint16_t *perm = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8);                     // [npad]
-            const int npad = P.npad;
-            for (int j = tid; j < n; j += T) keys[j] = osd_key(llr[j]);
-            for (int j = tid; j < npad; j += T) perm[j] = (j < n) ? (uint16_t)j : (uint16_t)0xFFFF;
+            uint16_t *perm = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8);                     // [n]
+            const int half = P.npad >> 1;
+            for (int j = tid; j < n; j += T) { keys[j] = osd_key(llr[j]); perm[j] = (uint16_t)j; }
             __syncthreads();
-            for (int size = 2; size <= npad; size <<= 1)
+            for (int size = 2; size <= P.npad; size <<= 1)
                 for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (int t = tid; t < (npad >> 1); t += T) {
-                        const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), p = i | stride;
-                        const uint16_t ia = perm[i], ib = perm[p];
-                        const unsigned long long ka = (ia == 0xFFFF) ? ~0ull : keys[ia], kb = (ib == 0xFFFF) ? ~0ull : keys[ib];
-                        const bool gt = (ka > kb) || (ka == kb && ia > ib);
-                        if (gt == ((i & size) == 0)) { perm[i] = ib; perm[p] = ia; }
+                    const bool mirror = (stride == (size >> 1));
+                    for (int t0 = tid; t0 < half; t0 += 4 * T) {
+                        int ii[4], pq[4];
+                        bool ok[4];
+                        unsigned long long ka[4], kb[4];
+                        uint16_t ia[4], ib[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int t = t0 + u * T, lo = t & (stride - 1), i = ((t - lo) << 1) | lo;
+                            const int p2 = mirror ? (i ^ (size - 1)) : (i | stride);
+                            ok[u] = (t < half) && (p2 < n);                                       // i < p2; a partner in the padding is +inf: no exchange
+                            ii[u] = ok[u] ? i : 0; pq[u] = ok[u] ? p2 : 0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { ka[u] = keys[ii[u]]; kb[u] = keys[pq[u]]; ia[u] = perm[ii[u]]; ib[u] = perm[pq[u]]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (ok[u] && ((ka[u] > kb[u]) || (ka[u] == kb[u] && ia[u] > ib[u]))) {
+                                keys[ii[u]] = kb[u]; keys[pq[u]] = ka[u]; perm[ii[u]] = ib[u]; perm[pq[u]] = ia[u];
+                            }
                     }
                     __syncthreads();
                 }
@@ -826,7 +842,8 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 for (int q = tid; q < m + 2; q += T) {
                     if (q == m) continue;
                     for (int k = 0; k < nops; k++) {
-                        const int a = opa[k], pp = opp[k], wa = a >> 6, wp = pp >> 6;
+                        const int a = __builtin_amdgcn_readfirstlane(opa[k]), pp = __builtin_amdgcn_readfirstlane(opp[k]), wa = a >> 6, wp = pp >> 6;
+                        const unsigned long long *mk = R + __builtin_amdgcn_readfirstlane(opt[k]) * mw;
                         const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
                         unsigned long long xa = U[uswz(q, wa, mw)];
                         const unsigned long long xp = (wp == wa) ? xa : U[uswz(q, wp, mw)];
@@ -835,9 +852,18 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                             if (wp == wa) { U[uswz(q, wa, mw)] = xa ^ abit ^ pbit; }
                             else { U[uswz(q, wa, mw)] = xa ^ abit; U[uswz(q, wp, mw)] = xp ^ pbit; }
                         }
-                        if (bp) {                                            // bit a after the swap
-                            const unsigned long long *mk = R + opt[k] * mw;
-                            for (int w = 0; w < mw; w++) U[uswz(q, w, mw)] ^= mk[w];
+                        if (bp) {                                            // bit a after the swap: add the pivot row (kernels.py:88-92)
+                            if (mw == 16) {                                  // all 32 reads in flight before the first XOR (a rolled loop waits per word)
+                                unsigned long long u[16];
+#pragma unroll
+                                for (int w = 0; w < 16; w++) u[w] = U[q * 16 + (w ^ (q & 15))];
+#pragma unroll
+                                for (int w = 0; w < 16; w++) u[w] ^= mk[w];
+#pragma unroll
+                                for (int w = 0; w < 16; w++) U[q * 16 + (w ^ (q & 15))] = u[w];
+                            } else {
+                                for (int w = 0; w < mw; w++) U[uswz(q, w, mw)] ^= mk[w];
+                            }
                         }
                     }
                 }
@@ -853,10 +879,16 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     for (int c2 = c0 + tid; c2 < L; c2 += T) {
                         if (!alive[c2]) continue;
                         const uint16_t *cr2 = colrows + c2 * cd;
+                        int rr[8];                                           // the column's support once (cd <= 8; short columns point at the zero row m)
+#pragma unroll
+                        for (int d = 0; d < 8; d++) rr[d] = (d < cd) ? (int)cr2[d] : m;
                         unsigned long long any = 0ull;
                         for (int w = wq; w < mw; w++) {
-                            unsigned long long x = 0ull;
-                            for (int d = 0; d < cd; d++) x ^= U[uswz(cr2[d], w, mw)];
+                            unsigned long long xs[8];
+#pragma unroll
+                            for (int d = 0; d < 8; d++) xs[d] = U[uswz(rr[d], w, mw)];
+                            unsigned long long x = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
+                            for (int d = 8; d < cd; d++) x ^= U[uswz(cr2[d], w, mw)];     // columns heavier than 8 (not the circuit-level matrices)
                             any |= (w == wq) ? (x & (~0ull << (row & 63))) : x;
                         }
                         if (!any) alive[c2] = 0;
@@ -912,7 +944,7 @@ static bool plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
     P.m = g->m; P.n = g->n; P.mw = (g->m + 63) / 64; P.K = 1024; P.cdeg = std::max(g->max_col_deg, 1);
     P.npad = 1;
     while (P.npad < g->n) P.npad <<= 1;
-    size_t off = std::max((size_t)(g->m + 2) * P.mw * 8, (size_t)g->n * 8 + (size_t)P.npad * 2);     // U, aliased by the sort scratch
+    size_t off = std::max((size_t)(g->m + 2) * P.mw * 8, (size_t)g->n * 10 + 16);     // U, aliased by the sort scratch (keys + indices)
     off = (size_t)round_up((int64_t)off, 16);
     P.offIdx = (int)off; off += (size_t)P.K * 2;
     P.offAlive = (int)off; off += (size_t)P.K;
