@@ -358,7 +358,7 @@ class CircuitPlan:
     decode of both sectors, OSD-0, logical comparison and tally, all on the device."""
 
     def __init__(self, compiled, Lx, Lz, graph_z, graph_x, prior_z, prior_x, logmask_z, logmask_x, p, max_iter=50, alpha_z=1.0, alpha_x=1.0,
-                 alpha_mode="dynamical", damping=1.0, clip_llr=20.0, use_osd=True, flags=0, batch=4096):
+                 alpha_mode="dynamical", damping=1.0, clip_llr=20.0, use_osd=True, flags=0, batch=16384):
         mode, az, sz = alpha_args(alpha_mode, alpha_z)
         _, ax, sx = alpha_args(alpha_mode, alpha_x)
         keep = {k: i32(_attr(compiled, k)) for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions",

@@ -134,6 +134,9 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double wmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// second operand uniform (held in scalar registers): avoids a VGPR copy of the clip bound per edge
+__device__ __forceinline__ double wmin_s(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }
+__device__ __forceinline__ double wmax_s(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }
 __device__ __forceinline__ double wmin_abs2(double a, double b) { double r; asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double wmax_abs2(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double flip_sign(double x, uint32_t signword) { return __hiloint2double(__double2hiint(x) ^ (int)signword, __double2loint(x)); }
@@ -165,7 +168,7 @@ __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int
                     const double r = flip_sign(mag, (pw >> u) << 31);                        // R_{it-1}[e], kernels.py:311-314
                     x = v[u] - r;                                                            // kernels.py:325
                     if (NANSEL) x = (x != x) ? 0.0 : x;                                      // kernels.py:328-329
-                    x = wmax(wmin(x, clip), nclip);                                          // kernels.py:330-333
+                    x = wmax_s(wmin_s(x, clip), nclip);                                      // kernels.py:330-333
                 }
                 cb |= ((uint32_t)__double2hiint(x) >> 31) << u;                              // x is never -0.0 or NaN here (see above)
                 if (fabs(x) < min1) arg = k0 + u;                                            // kernels.py:301-304 (strict: first minimum wins)

@@ -16,8 +16,8 @@ from qldpc_amd.simulation.engine import prior_llrs  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--tag", default="circ144")
-ap.add_argument("--trials", type=int, default=4096)
-ap.add_argument("--batch", type=int, default=2048)
+ap.add_argument("--trials", type=int, default=65536)
+ap.add_argument("--batch", type=int, default=16384)
 ap.add_argument("--max-iter", type=int, default=50)
 ap.add_argument("--no-osd", action="store_true")
 ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
