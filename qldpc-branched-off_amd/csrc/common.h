@@ -79,5 +79,10 @@ struct qldpc_graph {
     // workspace cache for the decode kernels (guarded by mu; one decode at a time per graph handle)
     mutable std::mutex mu;
     mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_alpha, ws_misc;
+    mutable std::mutex mu_io;        // host-pointer entry points: serialises use of ws_io (taken before mu)
+    mutable qldpc::DevBuf ws_io;
+    mutable std::vector<double> alpha_host;   // alpha table currently in ws_alpha (guarded by mu)
+    mutable void *pin = nullptr;     // pinned host staging for small results
+    mutable size_t pin_cap = 0;
     mutable int gf2_rank = -1;       // rank of H over GF(2), computed on first OSD use
 };

@@ -3,6 +3,7 @@
 #include "minsum_common.h"
 
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace qldpc {
@@ -81,9 +82,13 @@ static int decode_dev_impl(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     if ((rc = build_alpha_table(max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, tab)) != QLDPC_OK) return rc;
     std::lock_guard<std::mutex> lk(g->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if ((rc = g->ws_alpha.ensure(tab.size() * sizeof(double))) != QLDPC_OK) return rc;
-    QLDPC_HIP_TRY(hipMemcpyAsync(g->ws_alpha.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    QLDPC_HIP_TRY(hipStreamSynchronize(s));   // tab is a stack temporary: the copy must have left host memory
+    if (tab != g->alpha_host) {               // the table on the device is reused while the alpha schedule does not change
+        if ((rc = g->ws_alpha.ensure(tab.size() * sizeof(double))) != QLDPC_OK) return rc;
+        QLDPC_HIP_TRY(hipDeviceSynchronize());    // a decode (on any stream) still reading the old table must finish first
+        QLDPC_HIP_TRY(hipMemcpyAsync(g->ws_alpha.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        QLDPC_HIP_TRY(hipStreamSynchronize(s));   // tab is a stack temporary: the copy must have left host memory
+        g->alpha_host = tab;
+    }
     // prior_finite here means "host-verified clean prior" (finite, no -0.0); clip and alphas are checked the same way
     bool nanfree = prior_finite && std::isfinite(damping) && inputs_clean(nullptr, 0, clip_llr, tab.data(), max_iter);
     return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, g->ws_alpha.as<double>(), damping, clip_llr, flags, nanfree, d_err,
@@ -108,22 +113,44 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, cons
     if ((rc = use_device(g->device)) != QLDPC_OK) return rc;
     if (B == 0) return QLDPC_OK;
     const size_t m = g->m, n = g->n;
-    DevTmp d_synd, d_prior, d_err, d_llr, d_conv, d_iter;
-    if ((rc = d_synd.alloc(B * m)) || (rc = d_prior.alloc(n * 8)) || (rc = d_err.alloc(B * n)) || (rc = d_llr.alloc(B * n * 8)) ||
-        (rc = d_conv.alloc(B)) || (rc = d_iter.alloc(B * 4)))
-        return rc;
-    if (m) QLDPC_HIP_TRY(hipMemcpy(d_synd.p, syndromes, B * m, hipMemcpyHostToDevice));
-    if (n) QLDPC_HIP_TRY(hipMemcpy(d_prior.p, prior, n * 8, hipMemcpyHostToDevice));
+    // One grow-only device slab per graph handle (no hipMalloc / hipFree per call: the reference-style single-shot call is
+    // latency bound) laid out as  prior | syndromes | llr | iter | err | conv ; small results return in ONE copy through a
+    // pinned staging buffer, large ones directly into the caller's arrays.
+    const size_t o_prior = 0, o_synd = o_prior + round_up((int64_t)n * 8, 16), o_llr = o_synd + round_up((int64_t)B * m, 16),
+                 o_iter = o_llr + round_up((int64_t)B * n * 8, 16), o_err = o_iter + round_up((int64_t)B * 4, 16),
+                 o_conv = o_err + round_up((int64_t)B * n, 16), total = o_conv + round_up(B, 16);
+    std::unique_lock<std::mutex> io(g->mu_io);
+    if ((rc = g->ws_io.ensure(total)) != QLDPC_OK) return rc;
+    unsigned char *base = g->ws_io.as<unsigned char>();
+    if (m) QLDPC_HIP_TRY(hipMemcpyAsync(base + o_synd, syndromes, B * m, hipMemcpyHostToDevice, nullptr));
+    if (n) QLDPC_HIP_TRY(hipMemcpyAsync(base + o_prior, prior, n * 8, hipMemcpyHostToDevice, nullptr));
     const double one = 1.0;
     const bool prior_finite = inputs_clean(prior, (int)n, 1.0, &one, 1);
-    rc = decode_dev_impl(g, B, d_synd.as<int8_t>(), d_prior.as<double>(), max_iter, alpha_mode, alpha_val, alpha_seq,
-                         alpha_len, damping, clip_llr, flags, prior_finite, d_err.as<int8_t>(), d_llr.as<double>(),
-                         d_conv.as<uint8_t>(), d_iter.as<int32_t>(), nullptr);
+    rc = decode_dev_impl(g, B, reinterpret_cast<int8_t *>(base + o_synd), reinterpret_cast<double *>(base + o_prior), max_iter, alpha_mode,
+                         alpha_val, alpha_seq, alpha_len, damping, clip_llr, flags, prior_finite, reinterpret_cast<int8_t *>(base + o_err),
+                         reinterpret_cast<double *>(base + o_llr), reinterpret_cast<uint8_t *>(base + o_conv),
+                         reinterpret_cast<int32_t *>(base + o_iter), nullptr);
     if (rc != QLDPC_OK) return rc;
-    QLDPC_HIP_TRY(hipDeviceSynchronize());
-    if (n) QLDPC_HIP_TRY(hipMemcpy(out_err, d_err.p, B * n, hipMemcpyDeviceToHost));
-    if (n) QLDPC_HIP_TRY(hipMemcpy(out_llr, d_llr.p, B * n * 8, hipMemcpyDeviceToHost));
-    QLDPC_HIP_TRY(hipMemcpy(out_conv, d_conv.p, B, hipMemcpyDeviceToHost));
-    QLDPC_HIP_TRY(hipMemcpy(out_iter, d_iter.p, B * 4, hipMemcpyDeviceToHost));
+    const size_t out_bytes = total - o_llr;
+    if (out_bytes <= ((size_t)1 << 20)) {
+        if (g->pin_cap < out_bytes) {
+            if (g->pin) (void)hipHostFree(g->pin);
+            g->pin = nullptr; g->pin_cap = 0;
+            QLDPC_HIP_TRY(hipHostMalloc(&g->pin, (size_t)1 << 20, hipHostMallocDefault));
+            g->pin_cap = (size_t)1 << 20;
+        }
+        QLDPC_HIP_TRY(hipMemcpyAsync(g->pin, base + o_llr, out_bytes, hipMemcpyDeviceToHost, nullptr));
+        QLDPC_HIP_TRY(hipStreamSynchronize(nullptr));
+        const unsigned char *h = static_cast<const unsigned char *>(g->pin);
+        if (n) std::memcpy(out_llr, h, B * n * 8);
+        std::memcpy(out_iter, h + (o_iter - o_llr), B * 4);
+        if (n) std::memcpy(out_err, h + (o_err - o_llr), B * n);
+        std::memcpy(out_conv, h + (o_conv - o_llr), B);
+    } else {
+        if (n) QLDPC_HIP_TRY(hipMemcpy(out_llr, base + o_llr, B * n * 8, hipMemcpyDeviceToHost));
+        QLDPC_HIP_TRY(hipMemcpy(out_iter, base + o_iter, B * 4, hipMemcpyDeviceToHost));
+        if (n) QLDPC_HIP_TRY(hipMemcpy(out_err, base + o_err, B * n, hipMemcpyDeviceToHost));
+        QLDPC_HIP_TRY(hipMemcpy(out_conv, base + o_conv, B, hipMemcpyDeviceToHost));
+    }
     return QLDPC_OK;
 }
