@@ -629,6 +629,7 @@ struct OsdLdsArgs {
     const int8_t *synd; const double *llr; const int8_t *hard; const int32_t *ordering;
     int8_t *solution;
     uint16_t *ordws;               // [grid][n] sorted column order of the shot in flight (global, L2-resident)
+    int *queue;                    // next list entry to process (zeroed before the launch): work is handed out one shot at a time
     unsigned long long *dbg;       // optional counters: [0] shots, [1] chunks, [2] columns swept, [3] pivots, [4] cycles, [5] kill passes, [6] blocks
     int offIdx, offAlive, offRows, offPc, offR, offBlk, offMisc;
 };
@@ -670,7 +671,12 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     const int brow = m + 1;                                                // U row that carries b
 
     const int total = *P.count;
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    int *s_item = reinterpret_cast<int *>(stp + kOsdBlock);                  // the list entry this workgroup processes next
+    for (;;) {
+        if (tid == 0) *s_item = atomicAdd(P.queue, 1);
+        __syncthreads();
+        const int item = *s_item;
+        if (item >= total) break;
         const int64_t shot = P.list[item];
         const double *llr = P.llr + shot * n;
         const int8_t *hard = P.hard + shot * n, *synd = P.synd + shot * m;
@@ -951,7 +957,7 @@ static bool plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
     P.offRows = (int)off; off += (size_t)P.K * P.cdeg * 2;
     P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
     P.offR = (int)off; off += (size_t)kOsdBlock * P.mw * 8;
-    P.offBlk = (int)off; off += (4 + 6 * kOsdBlock) * 4;
+    P.offBlk = (int)off; off += (4 + 6 * kOsdBlock + 4) * 4;
     P.offMisc = (int)off; off += 64;
     lds = off + 16;
     return lds <= 160 * 1024;
@@ -986,6 +992,9 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     }
     P.nokill = getenv("QLDPC_OSD_NOKILL") ? 1 : 0;
     const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m + 2, 256), 64));
+    if ((rc = g->ws_queue.ensure(16)) != QLDPC_OK) return rc;
+    P.queue = g->ws_queue.as<int>() + 2;
+    QLDPC_HIP_TRY(hipMemsetAsync(P.queue, 0, 4, stream));
     static bool attr = false;
     if (!attr) { QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL(osd0_lds_kernel, dim3(grid), dim3(block), lds, stream, P);

@@ -28,6 +28,8 @@ struct WgArgs {
     double clip;
     int8_t *out_err; double *out_llr; uint8_t *out_conv; int32_t *out_iter;
     int offP, offI, offF;
+    int *queue;            // next shot to decode (zeroed before the launch): shots are handed out one at a time, so the
+                           // workgroups finish together although their shots run 1..max_iter iterations
 };
 
 
@@ -40,7 +42,11 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
     const int m = A.m, n = A.n, max_iter = A.max_iter, tid = threadIdx.x, T = blockDim.x;
     const double clip = A.clip;
 
-    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+    for (;;) {
+        if (tid == 0) unsat[2] = atomicAdd(A.queue, 1);                                       // unsat[2]: the shot this workgroup decodes next
+        __syncthreads();
+        const int64_t b = unsat[2];
+        if (b >= A.B) break;
         for (int j = tid; j < n; j += T) V[j] = A.prior[j];                                  // Q_{-1} = prior[col] (kernels.py:263-265)
         if (tid < 2) unsat[tid] = 0;
         bool done = false;
@@ -192,7 +198,11 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     const int deg_own = (tid < m) ? A.indptr[tid + 1] - A.indptr[tid] : 0;                   // the thread's first row, constant over shots
     if (tid == 0) { SP[m] = make_double2(0.0, 0.0); SI[m] = make_uint2(0u, 0u); }            // dummy check read by padded column slots
 
-    for (int64_t b = blockIdx.x; b < A.B; b += gridDim.x) {
+    for (;;) {
+        if (tid == 0) unsat[2] = atomicAdd(A.queue, 1);                                       // unsat[2]: the shot this workgroup decodes next
+        __syncthreads();
+        const int64_t b = unsat[2];
+        if (b >= A.B) break;
         for (int j = tid; j < n; j += T) V[j] = A.prior[j];                                  // Q_{-1} = prior[col] (kernels.py:263-265)
         if (tid < 2) unsat[tid] = 0;
         const bool csyn_own = (tid < m) ? (A.synd[b * m + tid] & 1) : false;
@@ -311,6 +321,10 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     for (int i = 0; i < g->m; i++) has_deg1 = has_deg1 || (g->indptr[i + 1] - g->indptr[i] == 1);
     const int block = (g->m > 512 || g->n > 4096) ? 1024 : 512;
     const unsigned grid = (unsigned)std::min<int64_t>(B, 256 * 2);
+    int rcq = g->ws_queue.ensure(16);
+    if (rcq != QLDPC_OK) return rcq;
+    QLDPC_HIP_TRY(hipMemsetAsync(g->ws_queue.p, 0, 16, stream));
+    A.queue = g->ws_queue.as<int>();
     if (clean && !getenv("QLDPC_WG_GENERIC")) {
         if (has_deg1) hipLaunchKernelGGL(minsum_wg_lean_kernel<true>, dim3(grid), dim3(block), lds, stream, A);
         else hipLaunchKernelGGL(minsum_wg_lean_kernel<false>, dim3(grid), dim3(block), lds, stream, A);
