@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libqldpc_oracle.so")
+if os.environ.get("QLDPC_ORACLE_SO"):          # e.g. the -fsanitize build (make -C oracle asan)
+    _SO = os.environ["QLDPC_ORACLE_SO"]
 
 ALPHA_CONST, ALPHA_DYNAMIC, ALPHA_SEQ = 0, 1, 2
 
