@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Circuit-level run on a code whose decoding matrices exceed the LDS-resident kernels ([[288,12,18]], 18 cycles as in the reference's
+main.py): builds the matrices with the GPU builder, then times run_simulation.  python tools/kbench_big.py [--code bb288 --cycles 18 --trials 256]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: F401,E402
+import qldpc_amd  # noqa: F401,E402
+from qldpc_amd.data import load_code  # noqa: E402
+from qldpc_amd.codes.bb_code import BBCodeCircuit  # noqa: E402
+from qldpc_amd.noise.builder import build_decoding_matrices  # noqa: E402
+from qldpc_amd.simulation.engine import run_simulation  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--code", default="bb288")
+ap.add_argument("--cycles", type=int, default=18)
+ap.add_argument("--trials", type=int, default=256)
+ap.add_argument("--p", type=float, default=0.005)
+ap.add_argument("--batch", type=int, default=256)
+a = ap.parse_args()
+c = load_code(a.code)
+bb = dict(ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=a.cycles, **bb)
+t0 = time.perf_counter()
+M = build_decoding_matrices(cb, c["Lx"], c["Lz"], a.p, verbose=False)
+print(f"builder: {time.perf_counter() - t0:.1f}s  HdecZ {M['HdecZ'].shape} HdecX {M['HdecX'].shape}", flush=True)
+t0 = time.perf_counter()
+r = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], a.p, num_trials=a.trials, num_cycles=a.cycles, maxIter=50, precomputed_matrices=M,
+                   base_seed=5, batch=a.batch, **bb)
+dt = time.perf_counter() - t0
+t = r["tally"]
+print(f"{a.code} x {a.cycles} cycles: {a.trials / dt:.1f} trials/s ({dt:.1f}s) LER={r['logical_error_rate']:.3f} conv_z={t[4] / t[0]:.2f} osd={t[6]}+{t[7]} unsat={t[12]}+{t[13]}", flush=True)
