@@ -403,7 +403,8 @@ static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B,
     int rc;
     {
         std::lock_guard<std::mutex> lk(g->mu);
-        rc = minsum_decode_dispatch(g, B, syn.as<int8_t>(), prior.as<double>(), P->max_iter, alpha.as<double>(), P->damping, P->clip, P->flags,
+        rc = minsum_decode_dispatch(g, B, syn.as<int8_t>(), prior.as<double>(), P->max_iter, alpha.as<double>(), P->damping, P->clip,
+                                    (P->flags & 0xFFFF) | (P->nanfree ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0),
                                     P->nanfree, det.as<int8_t>(), llr.as<double>(), conv.as<uint8_t>(), iter.as<int32_t>(), s);
     }
     if (rc != QLDPC_OK || !P->use_osd) return rc;

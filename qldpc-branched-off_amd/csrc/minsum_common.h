@@ -16,6 +16,15 @@ __device__ __forceinline__ double clip_nan(double q, double clip) {
     return q;
 }
 
+// The reference evaluates  q_damped = damping * q_new + (1.0 - damping) * Q_old  even for damping == 1 (kernels.py:336).  Q_old of
+// iteration 0 is the UNCLIPPED prior, so for a column whose prior is +-inf or NaN the product 0.0 * Q_old is NaN: every message into
+// such a column's checks is NaN from iteration 1 on (NaN survives the second clip and 0.0 * NaN keeps it alive).  The kernels skip the
+// damping arithmetic when damping == 1 (exact for finite Q_old) and reproduce this case explicitly: q = NaN where the prior is not finite.
+__device__ __forceinline__ bool prior_not_finite(double p) { return !(fabs(p) < INFINITY); }
+
+// internal flag (upper half of `flags`): the caller verified on the host that every prior is finite
+#define QLDPC_FLAG_INTERNAL_PRIOR_FINITE 0x10000
+
 // reference src/decoding/kernels.py:339-342
 __device__ __forceinline__ double clip_only(double q, double clip) {
     if (q > clip) return clip;

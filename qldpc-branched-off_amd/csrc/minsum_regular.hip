@@ -109,6 +109,11 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
     int coff[CDEG];
 #pragma unroll
     for (int k = 0; k < CDEG; k++) coff[k] = has_check ? A.indices[A.indptr[member] + k] : 0;
+    unsigned cnf = 0u;                                     // bit k: the prior of the row's k-th column is not finite (see minsum_common.h)
+    if (!NANFREE && !DAMP) {
+#pragma unroll
+        for (int k = 0; k < CDEG; k++) if (has_check && prior_not_finite(A.prior[coff[k]])) cnf |= 1u << k;
+    }
     const int roff = has_check ? member * RST : 0;
     bool has_var[2];
     int vj[2], voff[2][VDEG];
@@ -185,7 +190,11 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
                             double t = x[k] - Rprev[k];                                        // kernels.py:325
                             if (!NANFREE) t = (t != t) ? 0.0 : t;                              // kernels.py:328-329
                             t = vmax(vmin(t, clip), nclip);                                    // kernels.py:330-333
-                            if (DAMP) t = vmax(vmin(damping * t + one_minus_d * Qold[k], clip), nclip);   // kernels.py:336-342
+                            if (DAMP) {                                                        // kernels.py:336-342
+                                const double qd = damping * t + one_minus_d * Qold[k];
+                                t = NANFREE ? vmax(vmin(qd, clip), nclip) : clip_only(qd, clip);       // a NaN (from a NaN Q_old) must survive the clip
+                            }
+                            if (!NANFREE && !DAMP && ((cnf >> k) & 1u)) t = NAN;               // kernels.py:336 with Q_old = +-inf
                             x[k] = t;
                         }
                     }

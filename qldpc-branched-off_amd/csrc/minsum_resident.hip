@@ -65,6 +65,13 @@ __global__ __launch_bounds__(1024) void minsum_resident_kernel(ResidentArgs A) {
             for (int k = 0; k < CDEG; k++) if (k < cdeg[c]) ccol[c][k] = A.indices[rs + k];
         }
     }
+    unsigned cnf[CPT];                                      // bit k: the prior of the row's k-th column is not finite (see minsum_common.h)
+#pragma unroll
+    for (int c = 0; c < CPT; c++) {
+        cnf[c] = 0u;
+#pragma unroll
+        for (int k = 0; k < CDEG; k++) if (crow[c] >= 0 && k < cdeg[c] && prior_not_finite(A.prior[ccol[c][k]])) cnf[c] |= 1u << k;
+    }
     int vcol[VPT], vdeg[VPT], vrpos[VPT][VDEG];
     double vprior[VPT];
 #pragma unroll
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(1024) void minsum_resident_kernel(ResidentArgs A) {
                                 double x = q[k];
                                 if (it > 0) {
                                     x = clip_nan(x - Rprev[c][k], clip);                    // kernels.py:325-333
+                                    if (!DAMP && ((cnf[c] >> k) & 1u)) x = NAN;             // kernels.py:336 with Q_old = +-inf
                                     if (DAMP) x = clip_only(damping * x + one_minus_d * Qold[c][k], clip);   // :336-342
                                 }
                                 if (DAMP) Qold[c][k] = x;

@@ -14,7 +14,7 @@
 namespace qldpc {
 
 struct StreamArgs {
-    int m, n, max_iter, fixed;
+    int m, n, max_iter, fixed, nfcheck;
     const int32_t *indptr, *indices;
     int64_t B, Bpad;
     const int8_t *synd;     // [B][m]
@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void minsum_stream_kernel(StreamArgs A) {
                         q = A.prior[col];                                                    // kernels.py:263-265 (not clipped)
                     } else {
                         q = clip_nan(vcur[(int64_t)col * S] - M[(int64_t)pos * S], clip);    // kernels.py:325-333
+                        if (!DAMP && A.nfcheck && prior_not_finite(A.prior[col])) q = NAN;   // kernels.py:336 with Q_old = +-inf (see minsum_common.h)
                         if (DAMP) {
                             q = damping * q + one_minus_d * Qo[(int64_t)pos * S];           // kernels.py:336
                             q = clip_only(q, clip);                                          // kernels.py:339-342
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(256) void minsum_stream_kernel(StreamArgs A) {
                     double q;
                     if (DAMP) q = Qo[(int64_t)pos * S];
                     else if (it == 0) q = A.prior[col];
-                    else q = clip_nan(vcur[(int64_t)col * S] - M[(int64_t)pos * S], clip);
+                    else {
+                        q = clip_nan(vcur[(int64_t)col * S] - M[(int64_t)pos * S], clip);
+                        if (A.nfcheck && prior_not_finite(A.prior[col])) q = NAN;
+                    }
                     const double sign_j = (q >= 0) ? 1.0 : -1.0;
                     const double mag = (pos == min1_pos) ? min2 : min1;
                     const double msg = alpha * (sign_prod * sign_j) * mag;                   // kernels.py:312-314
@@ -128,6 +132,7 @@ int minsum_stream_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, 
         const int64_t cnt = (B - off < chunk) ? (B - off) : chunk;
         StreamArgs A;
         A.m = g->m; A.n = g->n; A.max_iter = max_iter; A.fixed = (flags & QLDPC_FLAG_FIXED_ITERS) ? 1 : 0;
+        A.nfcheck = (flags & QLDPC_FLAG_INTERNAL_PRIOR_FINITE) ? 0 : 1;
         A.indptr = g->d_indptr; A.indices = g->d_indices;
         A.B = cnt; A.Bpad = chunk;
         A.synd = d_synd + off * g->m; A.prior = d_prior; A.alpha = d_alpha;

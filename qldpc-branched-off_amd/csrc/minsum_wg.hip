@@ -19,7 +19,7 @@
 namespace qldpc {
 
 struct WgArgs {
-    int m, n, max_iter, fixed, rdeg, cdeg;
+    int m, n, max_iter, fixed, rdeg, cdeg, nfcheck;
     const int32_t *indptr;
     const uint16_t *ell_col;
     const uint32_t *ell_var;
@@ -28,14 +28,17 @@ struct WgArgs {
     double clip;
     int8_t *out_err; double *out_llr; uint8_t *out_conv; int32_t *out_iter;
     int offP, offI, offF;
+    double *vglobal;       // VG kernels: posteriors V[n] per workgroup in HBM/L2 (graphs whose V does not fit next to the check states in LDS)
     int *queue;            // next shot to decode (zeroed before the launch): shots are handed out one at a time, so the
                            // workgroups finish together although their shots run 1..max_iter iterations
 };
 
 
+template <bool VG>
 __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
     extern __shared__ unsigned char lds[];
-    double *V = reinterpret_cast<double *>(lds);
+    double *V;
+    if (VG) V = A.vglobal + (size_t)blockIdx.x * A.n; else V = reinterpret_cast<double *>(lds);
     double2 *SP = reinterpret_cast<double2 *>(lds + A.offP);                       // (alpha*min1, alpha*min2) per check
     unsigned long long *SI = reinterpret_cast<unsigned long long *>(lds + A.offI); // bits 0-55 input signs, 56-62 argmin (127 = none), 63 total sign
     int *unsat = reinterpret_cast<int *>(lds + A.offF);
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
                             const double mag = (k == argp) ? p2p : p1p;                      // kernels.py:313
                             const double r = (spp != (bool)((ip >> k) & 1)) ? -mag : mag;    // R_{it-1}[e], kernels.py:311-314
                             x = clip_nan(v - r, clip);                                       // kernels.py:325-333
+                            if (A.nfcheck && prior_not_finite(A.prior[col])) x = NAN;        // kernels.py:336 with Q_old = +-inf (see minsum_common.h)
                         }
                         const bool neg = !(x >= 0.0);                                        // kernels.py:296-299
                         sp ^= neg;
@@ -186,10 +190,11 @@ __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int
     }
 }
 
-template <bool NANSEL>
+template <bool NANSEL, bool VG>
 __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     extern __shared__ unsigned char lds[];
-    double *V = reinterpret_cast<double *>(lds);
+    double *V;
+    if (VG) V = A.vglobal + (size_t)blockIdx.x * A.n; else V = reinterpret_cast<double *>(lds);
     double2 *SP = reinterpret_cast<double2 *>(lds + A.offP);        // (alpha*min1, alpha*min2), both already multiplied by the row's total sign; [m + 1]
     uint2 *SI = reinterpret_cast<uint2 *>(lds + A.offI);            // .x = sign bits 0-31, .y = sign bits 32-55 | argmin << 24; [m + 1]
     int *unsat = reinterpret_cast<int *>(lds + A.offF);
@@ -287,34 +292,40 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     }
 }
 
-static size_t wg_lds_bytes(const qldpc_graph *g, int &offP, int &offI, int &offF) {
-    offP = (int)round_up((int64_t)g->n * 8, 16);
+static size_t wg_lds_bytes(const qldpc_graph *g, bool vg, int &offP, int &offI, int &offF) {
+    offP = vg ? 0 : (int)round_up((int64_t)g->n * 8, 16);
     offI = offP + (g->m + 1) * 16;     // one spare check state: the target of empty column slots in the lean kernel
     offF = offI + (g->m + 1) * 8;
     return (size_t)offF + 16;
 }
 
-bool wg_supported(const qldpc_graph *g, double damping) {
-    if (damping != 1.0 || !g->d_ell_col || !g->d_ell_var) return false;
-    if (g->m <= 0 || g->n <= 0 || g->max_row_deg > 56) return false;
+// 0: not supported, 1: everything in LDS, 2: check states in LDS, posteriors in global memory
+static int wg_mode(const qldpc_graph *g, double damping) {
+    if (damping != 1.0 || !g->d_ell_col || !g->d_ell_var) return 0;
+    if (g->m <= 0 || g->n <= 0 || g->max_row_deg > 56) return 0;
     int a, b, c;
-    return wg_lds_bytes(g, a, b, c) <= 160 * 1024;
+    if (wg_lds_bytes(g, false, a, b, c) <= 160 * 1024 && !getenv("QLDPC_WG_VGLOBAL")) return 1;
+    return wg_lds_bytes(g, true, a, b, c) <= 160 * 1024 ? 2 : 0;
 }
+
+bool wg_supported(const qldpc_graph *g, double damping) { return wg_mode(g, damping) != 0; }
 
 int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
                      double clip, int flags, bool clean, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
     WgArgs A;
     A.m = g->m; A.n = g->n; A.max_iter = max_iter; A.fixed = (flags & QLDPC_FLAG_FIXED_ITERS) ? 1 : 0;
-    A.rdeg = g->max_row_deg; A.cdeg = g->max_col_deg;
+    A.rdeg = g->max_row_deg; A.cdeg = g->max_col_deg; A.nfcheck = (flags & QLDPC_FLAG_INTERNAL_PRIOR_FINITE) ? 0 : 1;
     A.indptr = g->d_indptr; A.ell_col = g->d_ell_col; A.ell_var = g->d_ell_var;
     A.B = B; A.synd = d_synd; A.prior = d_prior; A.alpha = d_alpha; A.clip = clip;
     A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;
-    const size_t lds = wg_lds_bytes(g, A.offP, A.offI, A.offF);
+    const bool vg = (wg_mode(g, 1.0) == 2);
+    const size_t lds = wg_lds_bytes(g, vg, A.offP, A.offI, A.offF);
     static bool attr_set = false;
     if (!attr_set) {
-        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(minsum_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(minsum_wg_lean_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(minsum_wg_lean_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const void *kernels[] = {reinterpret_cast<const void *>(minsum_wg_kernel<false>), reinterpret_cast<const void *>(minsum_wg_kernel<true>),
+                                 reinterpret_cast<const void *>(minsum_wg_lean_kernel<true, false>), reinterpret_cast<const void *>(minsum_wg_lean_kernel<false, false>),
+                                 reinterpret_cast<const void *>(minsum_wg_lean_kernel<true, true>), reinterpret_cast<const void *>(minsum_wg_lean_kernel<false, true>)};
+        for (const void *k : kernels) QLDPC_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     bool has_deg1 = false;
@@ -325,12 +336,18 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     if (rcq != QLDPC_OK) return rcq;
     QLDPC_HIP_TRY(hipMemsetAsync(g->ws_queue.p, 0, 16, stream));
     A.queue = g->ws_queue.as<int>();
-    if (clean && !getenv("QLDPC_WG_GENERIC")) {
-        if (has_deg1) hipLaunchKernelGGL(minsum_wg_lean_kernel<true>, dim3(grid), dim3(block), lds, stream, A);
-        else hipLaunchKernelGGL(minsum_wg_lean_kernel<false>, dim3(grid), dim3(block), lds, stream, A);
-    } else {
-        hipLaunchKernelGGL(minsum_wg_kernel, dim3(grid), dim3(block), lds, stream, A);
+    A.vglobal = nullptr;
+    if (vg) {
+        if ((rcq = g->ws_vals.ensure((size_t)grid * g->n * 8)) != QLDPC_OK) return rcq;
+        A.vglobal = g->ws_vals.as<double>();
     }
+    const bool lean = clean && !getenv("QLDPC_WG_GENERIC");
+    if (lean && has_deg1 && vg) hipLaunchKernelGGL((minsum_wg_lean_kernel<true, true>), dim3(grid), dim3(block), lds, stream, A);
+    else if (lean && has_deg1) hipLaunchKernelGGL((minsum_wg_lean_kernel<true, false>), dim3(grid), dim3(block), lds, stream, A);
+    else if (lean && vg) hipLaunchKernelGGL((minsum_wg_lean_kernel<false, true>), dim3(grid), dim3(block), lds, stream, A);
+    else if (lean) hipLaunchKernelGGL((minsum_wg_lean_kernel<false, false>), dim3(grid), dim3(block), lds, stream, A);
+    else if (vg) hipLaunchKernelGGL(minsum_wg_kernel<true>, dim3(grid), dim3(block), lds, stream, A);
+    else hipLaunchKernelGGL(minsum_wg_kernel<false>, dim3(grid), dim3(block), lds, stream, A);
     QLDPC_HIP_TRY(hipGetLastError());
     return QLDPC_OK;
 }

@@ -680,3 +680,84 @@ def test_circuit_level_full_size_properties(L, oracle, golden):
     # per-trial verdicts agree with the tally of the same range
     assert head[T["z_err"]] == np.count_nonzero(outcomes & 1) and head[T["x_err"]] == np.count_nonzero(outcomes & 2)
     assert head[T["total_err"]] == np.count_nonzero(outcomes)
+
+
+def test_workgroup_kernel_with_posteriors_in_global_memory(L, oracle, golden, monkeypatch):
+    """Graphs whose posteriors do not fit next to the check states in LDS keep V in HBM/L2 (minsum_wg_*<VG = true>).  Forced on the
+    golden circuit-level cases (bit-identical LLRs), then on a matrix that really needs it: [[288,12,18]] x 12 cycles (2016 x ~17.5K)."""
+    monkeypatch.setenv("QLDPC_WG_VGLOBAL", "1")
+    for tag in ("circ72", "circ144"):
+        g = golden(tag + "_decode")
+        from qldpc_amd.data import load_circuit_matrices
+        d = load_circuit_matrices(tag)
+        for s in "ZX":
+            n = int(d[f"Hdec{s}_shape"][1])
+            graph = L.Graph(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], n)
+            for flags in (0, L.FLAG_FIXED_ITERS):
+                err, conv, llr, it = L.minsum_decode_batch(graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), "dynamical", 1.0, flags=flags)
+                assert np.array_equal(err, g[f"{s}_err"]) and np.array_equal(conv.astype(bool), g[f"{s}_conv"].astype(bool))
+                assert np.array_equal(llr, g[f"{s}_llr"]) and np.array_equal(it, g[f"{s}_iter"]), (tag, s, flags)
+            # non-clean priors (a -0.0 and an infinity) take the generic kernel
+            pr = g[f"llrs_{s}"].copy(); pr[3] = -0.0; pr[7] = np.inf
+            e2, c2, l2, i2 = L.minsum_decode_batch(graph, g[f"{s}_syndromes"][:2], pr, 20, "dynamical", 1.0)
+            eo, co, lo, io = oracle.minsum_decode_batch(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], n, g[f"{s}_syndromes"][:2], pr, max_iter=20)
+            assert np.array_equal(e2, eo) and np.array_equal(l2, lo) and np.array_equal(i2, io)
+    monkeypatch.delenv("QLDPC_WG_VGLOBAL")
+    from qldpc_amd.data import load_code
+    from qldpc_amd.codes.bb_code import BBCodeCircuit
+    from qldpc_amd.noise.builder import build_decoding_matrices
+    from qldpc_amd.simulation.engine import prior_llrs
+    c = load_code("bb288")
+    cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=12, ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"],
+                       b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+    M = build_decoding_matrices(cb, c["Lx"], c["Lz"], 0.003, verbose=False)
+    ip, ix, shape = L.canonical_csr(M["HdecZ"])
+    m, n = shape
+    assert n * 8 + 24 * m > 160 * 1024                      # V does not fit: the VG kernel is the one that runs
+    graph = L.Graph(ip, ix, n)
+    prior = prior_llrs(np.asarray(M["channel_probsZ"], dtype=np.float64))
+    rng = np.random.default_rng(8)
+    E = (rng.random((6, n)) < 0.0015).astype(np.int8)
+    E[0] = 0
+    synd = oracle.syndrome_check_batch(ip, ix, E) if hasattr(oracle, "syndrome_check_batch") else np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+    err, conv, llr, it = L.minsum_decode_batch(graph, synd, prior, 30, "dynamical", 1.0)
+    eo, co, lo, io = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=30)
+    assert np.array_equal(err, eo) and np.array_equal(llr, lo) and np.array_equal(it, io) and np.array_equal(conv.astype(bool), co.astype(bool))
+    assert conv[0] and conv.sum() >= 2
+
+
+def test_non_finite_priors_follow_the_reference(L, oracle, golden, monkeypatch):
+    """The reference evaluates damping * q + (1 - damping) * Q_old even for damping == 1 (kernels.py:336); Q_old of iteration 0 is the
+    unclipped prior, so a +-inf / NaN prior turns every later message of that column into NaN.  All kernels reproduce that (bit-exact
+    against the oracle's literal arithmetic), with and without damping."""
+    from qldpc_amd.data import load_code, load_circuit_matrices
+    rng = np.random.default_rng(99)
+    cases = []
+    for tag in ("bb144", "steane"):
+        c = load_code(tag)
+        cases.append((tag, c["Hx_indptr"], c["Hx_indices"], int(c["n"]), [0, L.FLAG_KERNEL_GENERIC, L.FLAG_KERNEL_STREAM] if tag == "bb144" else [0, L.FLAG_KERNEL_STREAM]))
+    d = load_circuit_matrices("circ72")
+    cases.append(("circ72", d["HdecZ_indptr"], d["HdecZ_indices"], int(d["HdecZ_shape"][1]), [0, L.FLAG_KERNEL_STREAM, "vg"]))
+    for tag, ip, ix, n, kernels in cases:
+        graph = L.Graph(ip, ix, n)
+        m = len(ip) - 1
+        E = (rng.random((5, n)) < 0.03).astype(np.int8)
+        synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+        base = np.log((1 - 0.03) / 0.03) + rng.normal(0, 0.3, n)
+        for variant in ("inf", "mixed"):
+            pr = base.copy()
+            pr[rng.integers(0, n)] = np.inf
+            if variant == "mixed":
+                pr[rng.integers(0, n)] = -np.inf; pr[rng.integers(0, n)] = np.nan; pr[rng.integers(0, n)] = -0.0
+            for damping, clip, iters in ((1.0, 20.0, 12), (0.75, 9.0, 8)):
+                eo, co, lo, io = oracle.minsum_decode_batch(ip, ix, n, synd, pr, max_iter=iters, damping=damping, clip_llr=clip)
+                for kern in kernels:
+                    if kern == "vg":
+                        monkeypatch.setenv("QLDPC_WG_VGLOBAL", "1")
+                        fl = 0
+                    else:
+                        fl = kern
+                    e2, c2, l2, i2 = L.minsum_decode_batch(graph, synd, pr, iters, "dynamical", 1.0, damping=damping, clip_llr=clip, flags=fl)
+                    monkeypatch.delenv("QLDPC_WG_VGLOBAL", raising=False)
+                    assert np.array_equal(i2, io) and np.array_equal(e2, eo), (tag, variant, damping, kern)
+                    assert np.array_equal(np.isnan(l2), np.isnan(lo)) and np.array_equal(l2[~np.isnan(lo)], lo[~np.isnan(lo)]), (tag, variant, damping, kern)
