@@ -629,6 +629,8 @@ struct OsdLdsArgs {
     const int8_t *synd; const double *llr; const int8_t *hard; const int32_t *ordering;
     int8_t *solution;
     uint16_t *ordws;               // [grid][n] sorted column order of the shot in flight (global, L2-resident)
+    unsigned long long *ug;        // UG kernels: [grid][(m + 2) * mw] row transform in HBM/L2, followed by [grid][n] sort keys
+    unsigned long long *ugkeys;
     int *queue;                    // next list entry to process (zeroed before the launch): work is handed out one shot at a time
     unsigned long long *dbg;       // optional counters: [0] shots, [1] chunks, [2] columns swept, [3] pivots, [4] cycles, [5] kill passes, [6] blocks
     int offIdx, offAlive, offRows, offPc, offR, offBlk, offMisc;
@@ -655,10 +657,13 @@ __device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw
 // a column).  The reduced form of a sparse column h is XOR_{i in supp h} U[i]; its pivot is simply the first set bit at a
 // position >= row (kernels.py:71-75); the swap row <-> pivot is a 2-bit swap in every row of U; the elimination
 // (kernels.py:88-92) is U[q] ^= mask for every q whose bit `row` is set.
+// UG = true: U (1 MB per shot for m = 2880) and the sort scratch live in global memory (one slab per workgroup); everything else is unchanged.
+template <bool UG>
 __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     extern __shared__ unsigned char lds[];
     const int m = P.m, n = P.n, mw = P.mw, K = P.K, cd = P.cdeg, tid = threadIdx.x, T = blockDim.x;
-    unsigned long long *U = reinterpret_cast<unsigned long long *>(lds);
+    unsigned long long *U;
+    if (UG) U = P.ug + (size_t)blockIdx.x * (size_t)(m + 2) * mw; else U = reinterpret_cast<unsigned long long *>(lds);
     uint16_t *sidx = reinterpret_cast<uint16_t *>(lds + P.offIdx);         // [K] columns of the current chunk
     uint8_t *alive = reinterpret_cast<uint8_t *>(lds + P.offAlive);        // [K]
     uint16_t *colrows = reinterpret_cast<uint16_t *>(lds + P.offRows);     // [K][cd] supports
@@ -687,8 +692,10 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
             // (key, index) pairs sorted IN PLACE (regular, conflict-free addresses; four independent compare-exchanges per thread in
             // flight).  Network: bitonic merges that are ascending everywhere (first step of a merge pairs i with its mirror
             // i ^ (size-1)), so the virtual +inf padding at positions >= n never moves and needs no storage.
-            unsigned long long *keys = reinterpret_cast<unsigned long long *>(lds);                 // [n]   (aliases U)
-            uint16_t *perm = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8);                     // [n]
+            unsigned long long *keys;                                                               // [n]   (LDS: aliases U)
+            uint16_t *perm;                                                                         // [n]
+            if (UG) { keys = P.ugkeys + (size_t)blockIdx.x * (size_t)(n + (n + 3) / 4); perm = reinterpret_cast<uint16_t *>(keys + n); }
+            else { keys = reinterpret_cast<unsigned long long *>(lds); perm = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8); }
             const int half = P.npad >> 1;
             for (int j = tid; j < n; j += T) { keys[j] = osd_key(llr[j]); perm[j] = (uint16_t)j; }
             __syncthreads();
@@ -780,8 +787,14 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 for (int x = tid; x < nb * mw; x += T) {
                     const int t = x / mw, w = x - t * mw;
                     const uint16_t *cr = colrows + bcol[t] * cd;
-                    unsigned long long acc = 0ull;
-                    for (int d = 0; d < cd; d++) acc ^= U[uswz(cr[d], w, mw)];
+                    int rr[8];
+                    unsigned long long xs[8];
+#pragma unroll
+                    for (int d = 0; d < 8; d++) rr[d] = (d < cd) ? (int)cr[d] : m;           // short columns point at the zero row m
+#pragma unroll
+                    for (int d = 0; d < 8; d++) xs[d] = U[uswz(rr[d], w, mw)];
+                    unsigned long long acc = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
+                    for (int d = 8; d < cd; d++) acc ^= U[uswz(cr[d], w, mw)];
                     R[t * mw + w] = acc;
                 }
                 __syncthreads();
@@ -794,22 +807,25 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 // this form: 1.36 M -- the cost is the dependent ballot -> scalar -> lane-read chain of a step, not the barrier.
                 int nops = 0, anydep = 0;
                 {
-                    const int wv = tid >> 6, lane = tid & 63, w = lane & 15, grp = lane >> 4, sc = 4 * wv + grp;
-                    const bool holder = wv < 4;
+                    // lanes per column: 16 / 32 / 64 for rows of <= 16 / 32 / 64 words; columns per wave 4 / 2 / 1; holder waves 4 / 8 / 16
+                    const int lsh = (mw <= 16) ? 4 : ((mw <= 32) ? 5 : 6), LPC = 1 << lsh, cpw = 64 >> lsh, osh = 6 - lsh;
+                    const unsigned long long gmask = (LPC == 64) ? ~0ull : ((1ull << LPC) - 1ull);
+                    const int wv = tid >> 6, lane = tid & 63, w = lane & (LPC - 1), grp = lane >> lsh, sc = cpw * wv + grp;
+                    const bool holder = wv < (kOsdBlock >> osh);
                     unsigned long long X = (holder && sc < nb && w < mw) ? R[sc * mw + w] : 0ull;
                     const int colid = (holder && sc < nb) ? (int)sidx[bcol[sc]] : 0;
                     int lrow = row;
                     for (int t = 0; t < nb; t++) {
-                        const int gt = t & 3;
-                        if (wv == (t >> 2)) {
+                        const int gt = t & (cpw - 1);
+                        if (wv == (t >> osh)) {
                             const bool ing = (grp == gt);
                             const int wq = lrow >> 6;
                             const unsigned long long mword = (!ing || w < wq) ? 0ull : ((w == wq) ? (X & (~0ull << (lrow & 63))) : X);
-                            const unsigned long long bal = (__ballot(mword != 0ull) >> (gt * 16)) & 0xFFFFull;
+                            const unsigned long long bal = (__ballot(mword != 0ull) >> (gt * LPC)) & gmask;
                             if (bal == 0ull) {                                                   // dependent on the pivots so far
-                                if (lane == gt * 16) { stp[t] = make_int2(-1, 0); alive[bcol[t]] = 0; }
+                                if (lane == gt * LPC) { stp[t] = make_int2(-1, 0); alive[bcol[t]] = 0; }
                             } else {
-                                const int pw = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal)), src = gt * 16 + pw;
+                                const int pw = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal)), src = gt * LPC + pw;
                                 const unsigned long long pword = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mword >> 32), src) << 32) |
                                                                  (unsigned)__builtin_amdgcn_readlane((int)mword, src);
                                 const int pp = pw * 64 + __builtin_ctzll(pword), a = lrow, wa = a >> 6, wp = pp >> 6;
@@ -820,20 +836,20 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                                 if (w == wp) rm = olda ? (rm | pbit) : (rm & ~pbit);
                                 if (w == wa) rm &= ~abit;
                                 if (ing) { X = rm; if (w < mw) R[t * mw + w] = rm; }
-                                if (lane == gt * 16) { stp[t] = make_int2(a, pp); opa[nops] = a; opp[nops] = pp; opt[nops] = t; pvcol[a] = (uint16_t)colid; }
+                                if (lane == gt * LPC) { stp[t] = make_int2(a, pp); opa[nops] = a; opp[nops] = pp; opt[nops] = t; pvcol[a] = (uint16_t)colid; }
                             }
                         }
                         __syncthreads();
                         const int2 st = stp[t];                                                  // both loads issue together: one LDS round trip
                         const unsigned long long rmw = (holder && w < mw) ? R[t * mw + w] : 0ull;
                         if (st.x < 0) { anydep = 1; continue; }
-                        if (holder && 4 * wv + 3 > t) {                                          // wave-uniform: this wave still holds a later column
+                        if (holder && cpw * wv + cpw - 1 > t) {                                  // wave-uniform: this wave still holds a later column
                             const int a = st.x, pp = st.y, wa = a >> 6, wp = pp >> 6;
                             const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
                             unsigned long long x = X;
                             // bits a / pp of a column live in the lanes holding words wa / wp of its group: two ballots instead of shuffles
                             const unsigned long long balA = __ballot(w == wa && (x & abit) != 0ull), balP = __ballot(w == wp && (x & pbit) != 0ull);
-                            const bool ba = (balA >> (grp * 16 + wa)) & 1ull, bp = (balP >> (grp * 16 + wp)) & 1ull;
+                            const bool ba = (balA >> (grp * LPC + wa)) & 1ull, bp = (balP >> (grp * LPC + wp)) & 1ull;
                             if (ba != bp) { if (w == wa) x ^= abit; if (w == wp) x ^= pbit; }
                             if (bp) x ^= rmw;                                                    // after the swap, bit a of the column is bp
                             if (sc > t && sc < nb) X = x;
@@ -868,7 +884,13 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
 #pragma unroll
                                 for (int w = 0; w < 16; w++) U[q * 16 + (w ^ (q & 15))] = u[w];
                             } else {
-                                for (int w = 0; w < mw; w++) U[uswz(q, w, mw)] ^= mk[w];
+                                for (int w0 = 0; w0 < mw; w0 += 8) {         // 8 words in flight (rows live in HBM/L2 in the UG kernel)
+                                    unsigned long long u[8];
+#pragma unroll
+                                    for (int j2 = 0; j2 < 8; j2++) u[j2] = (w0 + j2 < mw) ? U[uswz(q, w0 + j2, mw)] : 0ull;
+#pragma unroll
+                                    for (int j2 = 0; j2 < 8; j2++) if (w0 + j2 < mw) U[uswz(q, w0 + j2, mw)] = u[j2] ^ mk[w0 + j2];
+                                }
                             }
                         }
                     }
@@ -945,22 +967,26 @@ static int host_rank(const qldpc_graph *g) {
     return rank;
 }
 
-static bool plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
-    if (g->m > 1024 || g->n >= 65535 || g->m < 1) return false;
+// 0: not applicable (use the global-memory elimination), 1: U in LDS (m <= 1024), 2: U in HBM/L2 (m <= 4096, "UG")
+static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
+    if (g->m > 4096 || g->n >= 65535 || g->m < 1) return 0;
     P.m = g->m; P.n = g->n; P.mw = (g->m + 63) / 64; P.K = 1024; P.cdeg = std::max(g->max_col_deg, 1);
     P.npad = 1;
     while (P.npad < g->n) P.npad <<= 1;
-    size_t off = std::max((size_t)(g->m + 2) * P.mw * 8, (size_t)g->n * 10 + 16);     // U, aliased by the sort scratch (keys + indices)
-    off = (size_t)round_up((int64_t)off, 16);
-    P.offIdx = (int)off; off += (size_t)P.K * 2;
-    P.offAlive = (int)off; off += (size_t)P.K;
-    P.offRows = (int)off; off += (size_t)P.K * P.cdeg * 2;
-    P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
-    P.offR = (int)off; off += (size_t)kOsdBlock * P.mw * 8;
-    P.offBlk = (int)off; off += (4 + 6 * kOsdBlock + 4) * 4;
-    P.offMisc = (int)off; off += 64;
-    lds = off + 16;
-    return lds <= 160 * 1024;
+    for (int mode = (g->m <= 1024 && !getenv("QLDPC_OSD_UG")) ? 1 : 2; mode <= 2; mode++) {
+        size_t off = (mode == 1) ? std::max((size_t)(g->m + 2) * P.mw * 8, (size_t)g->n * 10 + 16) : 0;     // U, aliased by the sort scratch (keys + indices)
+        off = (size_t)round_up((int64_t)off, 16);
+        P.offIdx = (int)off; off += (size_t)P.K * 2;
+        P.offAlive = (int)off; off += (size_t)P.K;
+        P.offRows = (int)off; off += (size_t)P.K * P.cdeg * 2;
+        P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
+        P.offR = (int)off; off += (size_t)kOsdBlock * P.mw * 8;
+        P.offBlk = (int)off; off += (4 + 6 * kOsdBlock + 4) * 4;
+        P.offMisc = (int)off; off += 64;
+        lds = off + 16;
+        if (lds <= 160 * 1024) return mode;
+    }
+    return 0;
 }
 
 int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
@@ -968,13 +994,20 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     OsdLdsArgs P;
     size_t lds = 0;
     handled = false;
-    if (getenv("QLDPC_OSD_GLOBAL") || !plan_osd_lds(g, P, lds)) return QLDPC_OK;
+    const int mode = getenv("QLDPC_OSD_GLOBAL") ? 0 : plan_osd_lds(g, P, lds);
+    if (mode == 0) return QLDPC_OK;
     if (g->gf2_rank < 0) g->gf2_rank = host_rank(g);      // callers hold g->mu
     P.rankH = g->gf2_rank;
     const int grid = 512;
-    int rc = g->ws_misc.ensure((size_t)grid * g->n * 2 + 64);
+    const size_t sz_ord = (size_t)round_up((int64_t)grid * g->n * 2 + 64, 16);
+    const size_t sz_u = (mode == 2) ? (size_t)grid * (size_t)(g->m + 2) * P.mw * 8 : 0;
+    const size_t per_keys = (size_t)g->n + (size_t)(g->n + 3) / 4;                       // u64 units: n keys + n u16 indices
+    const size_t sz_k = (mode == 2) ? (size_t)grid * per_keys * 8 : 0;
+    int rc = g->ws_misc.ensure(sz_ord + sz_u + sz_k);
     if (rc != QLDPC_OK) return rc;
     P.ordws = g->ws_misc.as<uint16_t>();
+    P.ug = reinterpret_cast<unsigned long long *>(g->ws_misc.as<unsigned char>() + sz_ord);
+    P.ugkeys = reinterpret_cast<unsigned long long *>(g->ws_misc.as<unsigned char>() + sz_ord + sz_u);
     P.indptr = g->d_indptr; P.indices = g->d_indices; P.colptr = g->d_colptr; P.rowidx = g->d_rowidx;
     P.list = d_list; P.count = d_count; P.synd = d_synd; P.llr = d_llr; P.hard = d_hard; P.ordering = d_ordering; P.solution = d_solution;
     static unsigned long long *d_dbg = nullptr;
@@ -996,8 +1029,13 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     P.queue = g->ws_queue.as<int>() + 2;
     QLDPC_HIP_TRY(hipMemsetAsync(P.queue, 0, 4, stream));
     static bool attr = false;
-    if (!attr) { QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL(osd0_lds_kernel, dim3(grid), dim3(block), lds, stream, P);
+    if (!attr) {
+        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    if (mode == 2) hipLaunchKernelGGL(osd0_lds_kernel<true>, dim3(grid), dim3(1024), lds, stream, P);
+    else hipLaunchKernelGGL(osd0_lds_kernel<false>, dim3(grid), dim3(block), lds, stream, P);
     QLDPC_HIP_TRY(hipGetLastError());
     handled = true;
     return QLDPC_OK;

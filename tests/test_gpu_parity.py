@@ -761,3 +761,51 @@ def test_non_finite_priors_follow_the_reference(L, oracle, golden, monkeypatch):
                     monkeypatch.delenv("QLDPC_WG_VGLOBAL", raising=False)
                     assert np.array_equal(i2, io) and np.array_equal(e2, eo), (tag, variant, damping, kern)
                     assert np.array_equal(np.isnan(l2), np.isnan(lo)) and np.array_equal(l2[~np.isnan(lo)], lo[~np.isnan(lo)]), (tag, variant, damping, kern)
+
+
+def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch):
+    """OSD-0 for 1024 < m <= 4096: the row transform (1 MB per shot at m = 2880) lives in HBM/L2 (osd0_lds_kernel<UG = true>), pivots are
+    resolved with 32 / 64 lanes per column.  Forced on the golden circuit-level cases, then on matrices that need it, against the oracle
+    (consistent and inconsistent syndromes: the latter pin the reference's pivot-ROW choice, not just the pivot columns)."""
+    import ctypes as C
+    from qldpc_amd.decoding.osd import performOSD_enhanced
+    from qldpc_amd.data import load_code, load_circuit_matrices
+    monkeypatch.setenv("QLDPC_OSD_UG", "1")
+    for tag in ("circ72", "circ144"):
+        g = golden(tag + "_decode")
+        d = load_circuit_matrices(tag)
+        for s in "ZX":
+            ip, ix, n = d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], int(d[f"Hdec{s}_shape"][1])
+            H = L.csr_to_scipy(ip, ix, n) if hasattr(L, "csr_to_scipy") else None
+            from scipy.sparse import csr_matrix
+            H = csr_matrix((np.ones(len(ix), np.int8), ix, ip), shape=(len(ip) - 1, n))
+            for t, case in enumerate(g[f"{s}_osd_cases"]):
+                sol = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, ordering=g[f"{s}_osd_ordering"][t])
+                assert np.array_equal(sol, g[f"{s}_osd_solution"][t]), (tag, s, t)
+    monkeypatch.delenv("QLDPC_OSD_UG")
+    from qldpc_amd.codes.bb_code import BBCodeCircuit
+    from qldpc_amd.noise.builder import build_decoding_matrices
+    c = load_code("bb288")
+    rng = np.random.default_rng(3)
+    for cycles in (12, 18):                       # m = 2016 (32 words per row) and m = 2880 (45 words)
+        cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=cycles, ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"],
+                           b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+        M = build_decoding_matrices(cb, c["Lx"], c["Lz"], 0.004, verbose=False)
+        ip, ix, shape = L.canonical_csr(M["HdecX"])
+        m, n = shape
+        assert m > 1024
+        graph = L.Graph(ip, ix, n)
+        B = 4
+        E = (rng.random((B, n)) < 0.004).astype(np.int8)
+        synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+        synd[B - 1] = (rng.random(m) < 0.5)                          # almost surely outside the column space
+        llr = rng.normal(4.0, 3.0, (B, n)); llr[1, :50] = 0.0        # ties
+        hard = (rng.random((B, n)) < 0.002).astype(np.int8)
+        sol = np.zeros((B, n), np.int8)
+        L.check(L.lib().qldpc_osd0_batch(graph.handle, C.c_int64(B), L.ptr(synd, C.c_int8), L.ptr(llr, C.c_double), L.ptr(hard, C.c_int8), None,
+                                         L.ptr(sol, C.c_int8)))
+        for b in range(B):
+            want = oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b])
+            assert np.array_equal(sol[b], want), (cycles, b, int((sol[b] != want).sum()))
+            if b < B - 1:
+                assert np.array_equal(oracle.syndrome_check(ip, ix, sol[b]), synd[b])
