@@ -21,6 +21,7 @@ ap.add_argument("--batch", type=int, default=16384)
 ap.add_argument("--max-iter", type=int, default=50)
 ap.add_argument("--no-osd", action="store_true")
 ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
+ap.add_argument("--cpu-trials", type=int, default=0, help="also time the CPU checker (C port of the reference loop, all host threads) on this many trials")
 a = ap.parse_args()
 d = load_circuit_matrices(a.tag)
 c = load_code(str(d["code"]))
@@ -50,3 +51,18 @@ T = _lib.TALLY
 print(f"{a.tag} max_iter={a.max_iter} osd={not a.no_osd}: {a.trials / dt:.1f} trials/s ({dt:.2f}s); LER={t[T['total_err']] / t[0]:.3f} "
       f"conv_z={t[T['bp_conv_z']] / t[0]:.2f} conv_x={t[T['bp_conv_x']] / t[0]:.2f} osd={t[T['osd_z']]}+{t[T['osd_x']]} "
       f"mean_it_z={t[T['iters_z']] / t[0]:.1f} unsat={t[T['unsat_z']]}+{t[T['unsat_x']]}", flush=True)
+
+if a.cpu_trials > 0:
+    from oracle import oracle as orc            # CPU checker, timed beside the GPU path (never part of it)
+    with np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", a.tag + "_noise.npz")) as z:
+        g = {k: z[k] for k in z.files}          # the circuit arrays in the form the checker takes
+    circ = orc.make_circuit(g, g["Lx"], g["Lz"])
+    secs = [orc.make_sector(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], int(d[f"Hdec{s}_shape"][1]), orc.prior_llrs(d[f"channel_probs{s}"]),
+                            d[f"H{s}_logical_indptr"], d[f"H{s}_logical_indices"]) for s in "ZX"]
+    t0 = time.perf_counter()
+    ref = orc.circuit_sample_decode_tally(circ, secs[0], secs[1], 0.005, 5, 0, a.cpu_trials, max_iter=a.max_iter, use_osd=not a.no_osd, threads=0)
+    dt = time.perf_counter() - t0
+    chk = _lib.CircuitPlan(comp, c["Lx"], c["Lz"], gr[0], gr[1], pr[0], pr[1], mk[0], mk[1], 0.005, max_iter=a.max_iter, use_osd=not a.no_osd, batch=a.batch)
+    chk.run(5, 0, a.cpu_trials)
+    same = bool(np.array_equal(chk.read(), ref))
+    print(f"CPU port ({orc.num_threads()} threads): {a.cpu_trials / dt:.1f} trials/s ({dt:.1f}s); tally identical to the GPU's: {same}", flush=True)
