@@ -809,3 +809,81 @@ def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch
             assert np.array_equal(sol[b], want), (cycles, b, int((sol[b] != want).sum()))
             if b < B - 1:
                 assert np.array_equal(oracle.syndrome_check(ip, ix, sol[b]), synd[b])
+
+
+def test_random_irregular_graphs_all_kernels(L, oracle, monkeypatch):
+    """Differential sweep over seeded random Tanner graphs (ragged degrees, empty rows, isolated and degree-1 columns, duplicate rows) of
+    sizes that select every decoder: resident (small), workgroup-per-shot generic / lean in LDS and with posteriors in HBM/L2, streaming;
+    random alpha mode, iteration cap, clip, damping and priors (some zero, some negative).  Everything bit-identical to the oracle."""
+    rng = np.random.default_rng(2026)
+    shapes = [(5, 9, 3), (12, 30, 4), (40, 90, 5), (64, 200, 7), (150, 600, 6), (300, 2100, 9), (700, 5000, 12), (1100, 9000, 20)]
+    ran = {"vg": 0, "stream": 0}
+    for gi, (m, n, rd) in enumerate(shapes):
+        rows = []
+        for i in range(m):
+            d = 0 if (i % 17 == 5) else int(rng.integers(1, rd + 1))
+            rows.append(np.sort(rng.choice(n, size=min(d, n), replace=False)))
+        if m > 3:
+            rows[2] = rows[1].copy()                                   # duplicate check
+        ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+        ix = (np.concatenate(rows) if ip[-1] else np.zeros(0)).astype(np.int32)
+        graph = L.Graph(ip, ix, n)
+        B = int(rng.integers(3, 40))
+        E = (rng.random((B, n)) < 0.05).astype(np.int8)
+        synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+        synd[0] ^= (rng.random(m) < 0.3)                               # not necessarily a realisable syndrome
+        for trial in range(3):
+            prior = rng.normal(2.0, 2.0, n)
+            prior[rng.integers(0, n, 3)] = 0.0
+            if trial == 2:
+                prior[rng.integers(0, n)] = -0.0                       # non-clean: the generic kernels
+            mode, alpha = [("dynamical", 1.0), ("alvarado", float(rng.uniform(0.5, 1.0))), ("alvarado-autoregressive", rng.uniform(0.4, 1.0, 3))][trial]
+            damping = [1.0, 1.0, 0.8][int(rng.integers(0, 3))]
+            clip = float(rng.choice([20.0, 6.5, 50.0]))
+            iters = int(rng.integers(1, 25))
+            ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=iters, alpha=alpha, alpha_mode=mode, damping=damping, clip_llr=clip)
+            variants = [(0, None), (L.FLAG_FIXED_ITERS, None), (L.FLAG_KERNEL_STREAM, None)]
+            if n >= 2000:
+                variants.append((0, "1"))                              # posteriors in global memory
+            for flags, vg in variants:
+                if vg:
+                    monkeypatch.setenv("QLDPC_WG_VGLOBAL", vg)
+                    ran["vg"] += 1
+                out = L.minsum_decode_batch(graph, synd, prior, iters, mode, alpha, damping=damping, clip_llr=clip, flags=flags)
+                monkeypatch.delenv("QLDPC_WG_VGLOBAL", raising=False)
+                ran["stream"] += flags == L.FLAG_KERNEL_STREAM
+                for name, a, b in zip(("err", "conv", "llr", "iter"), (out[0], out[1].astype(bool), out[2], out[3]), (ref[0], ref[1].astype(bool), ref[2], ref[3])):
+                    assert np.array_equal(a, b, equal_nan=True), (gi, trial, flags, vg, name, mode, damping, clip, iters)
+    assert ran["vg"] >= 6 and ran["stream"] >= 20
+
+
+def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
+    """Differential sweep of OSD-0 over seeded random matrices (dependent rows, empty rows, heavy and empty columns, ties in |llr|,
+    realisable and unrealisable syndromes) through its three kernels: row transform in LDS, in HBM/L2 (forced), and the global-memory
+    elimination (forced).  Solutions identical to the oracle's."""
+    import ctypes as C
+    rng = np.random.default_rng(4242)
+    for gi, (m, n, dens) in enumerate(((4, 9, 0.4), (20, 60, 0.15), (63, 200, 0.06), (64, 64, 0.1), (130, 700, 0.03), (257, 1500, 0.012), (70, 40, 0.1))):
+        Hd = (rng.random((m, n)) < dens).astype(np.int8)
+        if m > 6:
+            Hd[5] = Hd[1] ^ Hd[2]; Hd[3] = 0
+        Hd[:, n // 2] = 0
+        ip, ix, shape = L.canonical_csr(Hd)
+        graph = L.Graph(ip, ix, n)
+        B = 9
+        E = (rng.random((B, n)) < 0.05).astype(np.int8)
+        synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+        synd[B - 1] = rng.random(m) < 0.5
+        synd[B - 2] = 0
+        llr = rng.normal(1.0, 3.0, (B, n)); llr[0, : n // 3] = 1.25; llr[1] = np.round(llr[1])     # ties
+        hard = (rng.random((B, n)) < 0.1).astype(np.int8)
+        want = np.stack([oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)])
+        for env in (None, "QLDPC_OSD_UG", "QLDPC_OSD_GLOBAL"):
+            if env:
+                monkeypatch.setenv(env, "1")
+            sol = np.zeros((B, n), np.int8)
+            L.check(L.lib().qldpc_osd0_batch(graph.handle, C.c_int64(B), L.ptr(synd, C.c_int8), L.ptr(llr, C.c_double), L.ptr(hard, C.c_int8), None,
+                                             L.ptr(sol, C.c_int8)))
+            if env:
+                monkeypatch.delenv(env)
+            assert np.array_equal(sol, want), (gi, env, np.flatnonzero((sol != want).any(1)))
