@@ -887,3 +887,42 @@ def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
             if env:
                 monkeypatch.delenv(env)
             assert np.array_equal(sol, want), (gi, env, np.flatnonzero((sol != want).any(1)))
+
+
+def _regular_graph(rng, m, cdeg, vdeg):
+    """(cdeg, vdeg)-regular bipartite graph from cdeg / vdeg column blocks of m columns, each block a sum of vdeg random distinct cyclic
+    shifts (row i meets columns blk * m + (i + s) mod m): no repeated edges by construction.  CSR with sorted rows."""
+    nblk = cdeg // vdeg
+    n = m * nblk
+    rows = np.zeros((m, cdeg), np.int64)
+    for blk in range(nblk):
+        shifts = rng.choice(m, size=vdeg, replace=False)
+        for t, sft in enumerate(shifts):
+            rows[:, blk * vdeg + t] = blk * m + (np.arange(m) + sft) % m
+    rows = np.sort(rows, axis=1)
+    return np.arange(0, m * cdeg + 1, cdeg, dtype=np.int32), rows.reshape(-1).astype(np.int32), n
+
+
+def test_other_regular_degrees(L, oracle):
+    """The branch-free kernel is instantiated for (6,3), (4,2) and (8,4)-regular graphs; the bivariate-bicycle codes only exercise (6,3).
+    Random (4,2) and (8,4) graphs: decode (all kernels) and the fused Monte-Carlo tally against the oracle."""
+    rng = np.random.default_rng(31)
+    for cdeg, vdeg, m in ((4, 2, 30), (4, 2, 64), (8, 4, 24), (8, 4, 60)):
+        ip, ix, n = _regular_graph(rng, m, cdeg, vdeg)
+        graph = L.Graph(ip, ix, n)
+        B = 257
+        E = (rng.random((B, n)) < 0.04).astype(np.int8)
+        synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+        prior = np.full(n, np.log(0.96 / 0.04))
+        for damping in (1.0, 0.85):
+            ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=30, damping=damping)
+            for flags in (0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_GENERIC, L.FLAG_KERNEL_STREAM):
+                out = L.minsum_decode_batch(graph, synd, prior, 30, "dynamical", 1.0, damping=damping, flags=flags)
+                for a, b in zip((out[0], out[1].astype(bool), out[2], out[3]), (ref[0], ref[1].astype(bool), ref[2], ref[3])):
+                    assert np.array_equal(a, b, equal_nan=True), (cdeg, vdeg, m, damping, flags)
+        Lmat = (rng.random((3, n)) < 0.3).astype(np.uint8)
+        want = oracle.cc_sample_decode_tally(ip, ix, n, Lmat, 0.03, 77, 5, 6000, max_iter=25, threads=0)
+        for flags in (0, L.FLAG_FIXED_ITERS, L.FLAG_MC_UNFUSED):
+            got = L.cc_sample_decode_tally(graph, Lmat, 0.03, 77, 5, 6000, max_iter=25, flags=flags)
+            assert np.array_equal(got, want), (cdeg, vdeg, m, flags, got.tolist(), want.tolist())
+        assert want[L.TALLY["osd_z"]] > 0
