@@ -926,3 +926,33 @@ def test_other_regular_degrees(L, oracle):
             got = L.cc_sample_decode_tally(graph, Lmat, 0.03, 77, 5, 6000, max_iter=25, flags=flags)
             assert np.array_equal(got, want), (cdeg, vdeg, m, flags, got.tolist(), want.tolist())
         assert want[L.TALLY["osd_z"]] > 0
+
+
+@pytest.mark.parametrize("code,cycles,p", [("bb90", 4, 0.004), ("bb108", 3, 0.006)])
+def test_other_codes_circuit_level_pipeline(L, oracle, code, cycles, p):
+    """The whole circuit-level path on the reference's other codes (k = 8 logicals, other lattice sizes): circuit generator -> builder
+    (GPU single-fault signatures) -> run_simulation; the tally equals the oracle's literal simulate-and-decode of the same Philox trials.
+    (The circuit arrays for these codes are not pinned by a reference fixture -- only [[72]] and [[144]] are -- this pins sampler + decoders.)"""
+    from qldpc_amd.data import load_code
+    from qldpc_amd.codes.bb_code import BBCodeCircuit
+    from qldpc_amd.noise.compiled import CompiledCircuit
+    from qldpc_amd.noise.builder import build_decoding_matrices
+    from qldpc_amd.simulation.engine import run_simulation, prior_llrs
+    c = load_code(code)
+    bb = dict(ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+    cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=cycles, **bb)
+    M = build_decoding_matrices(cb, c["Lx"], c["Lz"], p, verbose=False)
+    comp = CompiledCircuit(cb.get_full_circuit(), cb.cycle * 2, cb.lin_order, cb.data_qubits, cb.Xchecks, cb.Zchecks)
+    circ = oracle.make_circuit(comp, c["Lx"], c["Lz"])
+    k = c["Lx"].shape[0]
+    secs = []
+    for s in "ZX":
+        ip, ix, shape = L.canonical_csr(M[f"Hdec{s}"])
+        flr = int(M[f"first_logical_row{s}"])
+        lip, lix, _ = L.canonical_csr(np.asarray(M[f"H{s}_full"])[flr:flr + k])
+        secs.append(oracle.make_sector(ip, ix, shape[1], prior_llrs(np.asarray(M[f"channel_probs{s}"], dtype=np.float64)), lip, lix))
+    N = 300
+    res = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], p, num_trials=N, num_cycles=cycles, maxIter=40, precomputed_matrices=M, base_seed=123, batch=128, **bb)
+    ref = oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], p, 123, 0, N, max_iter=40, threads=0)
+    assert np.array_equal(res["tally"], ref), (res["tally"].tolist(), ref.tolist())
+    assert ref[0] == N and ref[L.TALLY["unsat_z"]] == 0 and ref[L.TALLY["unsat_x"]] == 0 and ref[L.TALLY["osd_z"]] + ref[L.TALLY["osd_x"]] > 0
