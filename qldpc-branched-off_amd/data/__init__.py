@@ -38,7 +38,8 @@ def load_code(tag):
 
 
 def load_circuit_matrices(tag):
-    """Circuit-level decoding matrices (tag 'circ72' or 'circ144', p = 0.005) in CSR form."""
+    """Circuit-level decoding matrices the reference cached at p = 0.005, in CSR form: tags circ72 (6 cycles), circ90 / circ108 (10),
+    circ144 (12), circ288 (18)."""
     with np.load(os.path.join(_HERE, f"{tag}_p005.npz")) as d:
         return {k: d[k] for k in d.files}
 

@@ -52,6 +52,10 @@ CODES = {
 CACHE = {
     "circ72": ("matrix_cache/matrices_61d7ee9cf7e4c9ee.npz", "bb72", 6, 0.005),
     "circ144": ("matrix_cache/matrices_d63ef327adf94be6.npz", "bb144", 12, 0.005),
+    # the reference's cached decoding matrices of its other experiments (main.py: num_cycles = distance), builder parity only
+    "circ90": ("matrix_cache/matrices_982970e639ed188c.npz", "bb90", 10, 0.005),
+    "circ108": ("matrix_cache/matrices_a7240995d9aa0955.npz", "bb108", 10, 0.005),
+    "circ288": ("matrix_cache/matrices_6c6f54237b5d8525.npz", "bb288", 18, 0.005),
 }
 
 

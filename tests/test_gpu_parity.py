@@ -407,7 +407,8 @@ def test_run_simulation_mirror(L, oracle, golden):
         assert r["z_logical_error_rate"] == per_trial[:stop, 1].sum() / stop and r["x_logical_error_rate"] == per_trial[:stop, 2].sum() / stop
 
 
-@pytest.mark.parametrize("tag,code,cycles", [("circ72", "bb72", 6), ("circ144", "bb144", 12)])
+@pytest.mark.parametrize("tag,code,cycles", [("circ72", "bb72", 6), ("circ144", "bb144", 12), ("circ90", "bb90", 10), ("circ108", "bb108", 10),
+                                             ("circ288", "bb288", 18)])
 def test_builder_reproduces_reference_matrix_cache(L, tag, code, cycles):
     """build_decoding_matrices (builder.py:69-176) against the matrices the REFERENCE cached (matrix_cache/*.npz, re-packed as CSR):
     same columns in the same order, bit-identical summed probabilities, same logical rows."""
@@ -419,14 +420,15 @@ def test_builder_reproduces_reference_matrix_cache(L, tag, code, cycles):
     cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=cycles, ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"],
                        b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
     M = build_decoding_matrices(cb, c["Lx"], c["Lz"], 0.005, verbose=False)
-    assert M["k"] == 12 and M["num_cycles"] == cycles
+    k = int(c["Lx"].shape[0])
+    assert M["k"] == k and M["num_cycles"] == cycles
     for s in "ZX":
         ip, ix, shape = L.canonical_csr(M[f"Hdec{s}"])
         assert tuple(shape) == tuple(int(x) for x in d[f"Hdec{s}_shape"])
         assert np.array_equal(ip, d[f"Hdec{s}_indptr"]) and np.array_equal(ix, d[f"Hdec{s}_indices"])
         assert np.array_equal(M[f"channel_probs{s}"], d[f"channel_probs{s}"])          # bitwise: same summation order
         flr = M[f"first_logical_row{s}"]
-        lip, lix, _ = L.canonical_csr(M[f"H{s}_full"][flr:flr + 12])
+        lip, lix, _ = L.canonical_csr(M[f"H{s}_full"][flr:flr + k])
         assert np.array_equal(lip, d[f"H{s}_logical_indptr"]) and np.array_equal(lix, d[f"H{s}_logical_indices"])
 
 
