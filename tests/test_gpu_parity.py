@@ -958,3 +958,58 @@ def test_other_codes_circuit_level_pipeline(L, oracle, code, cycles, p):
     ref = oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], p, 123, 0, N, max_iter=40, threads=0)
     assert np.array_equal(res["tally"], ref), (res["tally"].tolist(), ref.tolist())
     assert ref[0] == N and ref[L.TALLY["unsat_z"]] == 0 and ref[L.TALLY["unsat_x"]] == 0 and ref[L.TALLY["osd_z"]] + ref[L.TALLY["osd_x"]] > 0
+
+
+def _rank_run_simulation(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import json
+    import numpy as np
+    import torch  # noqa: F401  (before the HIP library)
+    import torch.distributed as dist
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd.data import load_code, load_precomputed_matrices
+    from qldpc_amd.simulation.engine import run_simulation
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = load_code("bb72")
+    bb = dict(ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+    M = load_precomputed_matrices("circ72")
+    out = {}
+    r = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=501, num_cycles=6, maxIter=30, precomputed_matrices=M, base_seed=77, batch=64, **bb)
+    out["plain"] = [int(x) for x in r["tally"]]
+    r = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=501, num_cycles=6, maxIter=30, precomputed_matrices=M, base_seed=77, batch=64,
+                       target_logical_errors=37, alpha_mode="alvarado", alpha_estimation_trials=200, **bb)
+    out["target"] = [r["num_trials"], r["logical_errors"], r["logical_error_rate"], r["alpha_r2_z"]]
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
+        json.dump(out, fh)
+    dist.destroy_process_group()
+
+
+def test_run_simulation_sharded_over_two_ranks(L, tmp_path):
+    """N > 1 on the real device path: two processes (gloo; they share this box's one GPU) each run their contiguous trial shard; the
+    all-reduced tally, the exact early stop and the estimated alpha are identical on both ranks and equal to the single-process run."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    from qldpc_amd.data import load_code, load_precomputed_matrices
+    from qldpc_amd.simulation.engine import run_simulation
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.get_context("spawn")
+    mp.spawn(_rank_run_simulation, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert got[0] == got[1]
+    c = load_code("bb72")
+    bb = dict(ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+    M = load_precomputed_matrices("circ72")
+    r = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=501, num_cycles=6, maxIter=30, precomputed_matrices=M, base_seed=77, batch=64, **bb)
+    assert [int(x) for x in r["tally"]] == got[0]["plain"]
+    r = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=501, num_cycles=6, maxIter=30, precomputed_matrices=M, base_seed=77, batch=64,
+                       target_logical_errors=37, alpha_mode="alvarado", alpha_estimation_trials=200, **bb)
+    assert [r["num_trials"], r["logical_errors"], r["logical_error_rate"], r["alpha_r2_z"]] == got[0]["target"]
+    assert r["logical_errors"] == 37 and r["num_trials"] < 501
