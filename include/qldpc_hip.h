@@ -108,6 +108,8 @@ int qldpc_bp_decode_batch(const qldpc_graph *g, int64_t B, const int8_t *syndrom
 
 /* a6: GF(2) syndrome SpMV  s = H e (kernels.py:222-231, 352-359; H_csr.dot(e)%2 in alpha.py:128): vectors[B][n] -> out[B][m] */
 int qldpc_gf2_spmv_batch(const qldpc_graph *g, int64_t B, const int8_t *vectors, int8_t *out);
+/* same on device pointers; only enqueues on `stream` (hipStream_t) */
+int qldpc_gf2_spmv_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_vectors, int8_t *d_out, void *stream);
 
 /* a7: gf2_elimination (kernels.py:5-34): Gauss-Jordan on B byte matrices A[B][m][n] (0/1), b[B][m], in place.
  * pivot_rows/pivot_cols: int64[B][min(m,n)], num_pivots int32[B]. */
@@ -122,6 +124,11 @@ int qldpc_gf2_eliminate_packed(int64_t B, int m, int n, int nwords, uint64_t *A,
  * ascending index (np.argsort's default kind leaves ties implementation-defined, osd.py:12). solution int8[B][n]. */
 int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *llr, const int8_t *hard,
                      const int32_t *ordering, int8_t *solution);
+/* same on device pointers; only enqueues on `stream`.  d_select / d_select_count (both NULL = all B shots): device list of the shots to
+ * solve and its device-resident length, e.g. the shots qldpc_minsum_decode_batch_dev left unconverged -- the decode -> OSD-0 hand-over of
+ * src/simulation/engine.py:96-97 without a host round trip.  Shots not listed keep whatever d_solution holds. */
+int qldpc_osd0_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_syndromes, const double *d_llr, const int8_t *d_hard,
+                         const int32_t *d_ordering, const int32_t *d_select, const int32_t *d_select_count, int8_t *d_solution, void *stream);
 /* f1: performOSD_enhanced(H, syndrome, llr, hard, order, max_combinations) (src/decoding/osd.py:5-77), batched.  The OSD-0 solution is
  * returned whenever it reproduces the syndrome (osd.py:27-29); otherwise the <= C(order+10, <= order) flip sets over the least
  * reliable non-pivot positions are scored with recompute_solution / compute_metric (src/decoding/kernels.py:195-219) and the

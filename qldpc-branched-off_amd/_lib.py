@@ -19,7 +19,7 @@ TALLY = {"trials": 0, "z_err": 1, "x_err": 2, "total_err": 3, "bp_conv_z": 4, "b
 EXPORTS = [
     "qldpc_last_error", "qldpc_version", "qldpc_device_count", "qldpc_graph_create", "qldpc_graph_destroy", "qldpc_graph_dims",
     "qldpc_minsum_decode_batch", "qldpc_minsum_decode_batch_dev", "qldpc_minsum_check_pass", "qldpc_bp_check_pass",
-    "qldpc_bp_decode_batch", "qldpc_gf2_spmv_batch", "qldpc_gf2_eliminate", "qldpc_gf2_eliminate_packed", "qldpc_osd0_batch", "qldpc_osdw_batch",
+    "qldpc_bp_decode_batch", "qldpc_gf2_spmv_batch", "qldpc_gf2_eliminate", "qldpc_gf2_eliminate_packed", "qldpc_osd0_batch", "qldpc_osd0_batch_dev", "qldpc_osdw_batch", "qldpc_gf2_spmv_batch_dev",
     "qldpc_noisy_circuit_batch", "qldpc_frame_sim_batch", "qldpc_sparsify_batch", "qldpc_cc_sample_decode_tally",
     "qldpc_cc_plan_create", "qldpc_cc_plan_run", "qldpc_cc_plan_read", "qldpc_cc_plan_kernel_time", "qldpc_cc_plan_destroy",
     "qldpc_philox4x32_10", "qldpc_circuit_plan_create", "qldpc_circuit_plan_run", "qldpc_circuit_plan_run_outcomes", "qldpc_circuit_plan_read", "qldpc_circuit_plan_sample",

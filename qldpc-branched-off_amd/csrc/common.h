@@ -78,7 +78,7 @@ struct qldpc_graph {
     uint32_t *d_ell_var = nullptr;   // [max_col_deg][n]  (row << 8) | position-in-row of the d-th edge of column j (ascending rows)
     // workspace cache for the decode kernels (guarded by mu; one decode at a time per graph handle)
     mutable std::mutex mu;
-    mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_alpha, ws_misc, ws_queue;
+    mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_alpha, ws_misc, ws_queue, ws_list;
     mutable std::mutex mu_io;        // host-pointer entry points: serialises use of ws_io (taken before mu)
     mutable qldpc::DevBuf ws_io;
     mutable std::vector<double> alpha_host;   // alpha table currently in ws_alpha (guarded by mu)

@@ -540,6 +540,29 @@ QLDPC_EXPORT int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t 
     return QLDPC_OK;
 }
 
+// device-pointer form of qldpc_osd0_batch: only enqueues on `stream`.  d_select (may be NULL = every shot) lists the shots to solve, e.g. the
+// ones a decode left unconverged; *d_select_count is read on the device, so no host round trip is needed between decode and OSD-0.
+QLDPC_EXPORT int qldpc_osd0_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_syndromes, const double *d_llr, const int8_t *d_hard,
+                                      const int32_t *d_ordering, const int32_t *d_select, const int32_t *d_select_count, int8_t *d_solution,
+                                      void *stream) {
+    QLDPC_REQUIRE(g != nullptr, "graph is NULL");
+    QLDPC_REQUIRE(B >= 0 && B < ((int64_t)1 << 31), "batch out of range");
+    QLDPC_REQUIRE((d_select == nullptr) == (d_select_count == nullptr), "d_select and d_select_count go together");
+    int rc = use_device(g->device);
+    if (rc != QLDPC_OK) return rc;
+    if (B == 0 || g->n == 0) return QLDPC_OK;
+    QLDPC_REQUIRE(d_llr && d_hard && d_solution && (d_syndromes || g->m == 0), "NULL buffer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (!d_select) {
+        if ((rc = g->ws_list.ensure((size_t)B * 4 + 16)) != QLDPC_OK) return rc;
+        int32_t *cnt = g->ws_list.as<int32_t>(), *list = cnt + 4;
+        hipLaunchKernelGGL(iota_list_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, list, cnt);
+        d_select = list; d_select_count = cnt;
+    }
+    return osd0_listed_launch(g, d_select, d_select_count, d_syndromes, d_llr, d_hard, d_ordering, d_solution, s);
+}
+
 // f1: batched performOSD_enhanced(order, max_combinations) (osd.py:5-77); order == 0 is qldpc_osd0_batch.
 QLDPC_EXPORT int qldpc_osdw_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *llr, const int8_t *hard,
                                   const int32_t *ordering, int order, int64_t max_combinations, int8_t *solution) {

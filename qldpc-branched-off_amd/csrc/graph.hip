@@ -147,7 +147,7 @@ QLDPC_EXPORT void qldpc_graph_destroy(qldpc_graph *g) {
         if (p) (void)hipFree(p);
     if (g->d_ell_col) (void)hipFree(g->d_ell_col);
     if (g->d_ell_var) (void)hipFree(g->d_ell_var);
-    g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_alpha.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release();
+    g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_alpha.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_list.release();
     if (g->pin) (void)hipHostFree(g->pin);
     delete g;
 }

@@ -337,6 +337,17 @@ QLDPC_EXPORT int qldpc_gf2_spmv_batch(const qldpc_graph *g, int64_t B, const int
     return QLDPC_OK;
 }
 
+// device-pointer form: only enqueues on `stream`
+QLDPC_EXPORT int qldpc_gf2_spmv_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_vectors, int8_t *d_out, void *stream) {
+    QLDPC_REQUIRE(g != nullptr, "graph is NULL");
+    QLDPC_REQUIRE(B >= 0, "negative batch");
+    int rc = use_device(g->device);
+    if (rc != QLDPC_OK) return rc;
+    if (B == 0 || g->m == 0) return QLDPC_OK;
+    QLDPC_REQUIRE(d_vectors != nullptr && d_out != nullptr, "NULL buffer");
+    return gf2_spmv_launch(g, B, d_vectors, d_out, reinterpret_cast<hipStream_t>(stream));
+}
+
 QLDPC_EXPORT void qldpc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }

@@ -1013,3 +1013,51 @@ def test_run_simulation_sharded_over_two_ranks(L, tmp_path):
                        target_logical_errors=37, alpha_mode="alvarado", alpha_estimation_trials=200, **bb)
     assert [r["num_trials"], r["logical_errors"], r["logical_error_rate"], r["alpha_r2_z"]] == got[0]["target"]
     assert r["logical_errors"] == 37 and r["num_trials"] < 501
+
+
+def test_device_resident_decode_osd_check_chain(L, oracle):
+    """decode -> OSD-0 on the unconverged shots -> syndrome check entirely on torch CUDA tensors and one non-default stream
+    (qldpc_minsum_decode_batch_dev, qldpc_osd0_batch_dev with a device-resident selection, qldpc_gf2_spmv_batch_dev): the device-side
+    analogue of _run_single_trial_fast (engine.py:86-100).  Results equal the oracle's per-shot pipeline."""
+    import ctypes as C
+    import torch
+    from qldpc_amd.data import load_code
+    c = load_code("bb144")
+    ip, ix, n, m = c["Hx_indptr"], c["Hx_indices"], c["n"], c["m"]
+    g = L.Graph(ip, ix, n)
+    rng = np.random.default_rng(19)
+    B = 600
+    E = (rng.random((B, n)) < 0.05).astype(np.int8)
+    synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+    prior = np.full(n, np.log(0.95 / 0.05))
+    err_o, conv_o, llr_o, it_o = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=15, threads=0)
+    want = err_o.copy()
+    for b in np.flatnonzero(conv_o == 0):
+        want[b] = oracle.osd0(ip, ix, n, synd[b], llr_o[b], err_o[b])
+    assert 20 < (conv_o == 0).sum() < B
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ds = torch.from_numpy(synd).cuda(); dp = torch.from_numpy(prior).cuda()
+        de = torch.empty((B, n), dtype=torch.int8, device="cuda"); dl = torch.empty((B, n), dtype=torch.float64, device="cuda")
+        dc = torch.empty(B, dtype=torch.uint8, device="cuda"); di = torch.empty(B, dtype=torch.int32, device="cuda")
+        dchk = torch.empty((B, m), dtype=torch.int8, device="cuda")
+        st.synchronize()
+        p = lambda t: C.c_void_p(t.data_ptr())       # noqa: E731
+        s = C.c_void_p(st.cuda_stream)
+        L.check(L.lib().qldpc_minsum_decode_batch_dev(g.handle, C.c_int64(B), p(ds), p(dp), C.c_int(15), C.c_int(L.ALPHA_DYNAMIC), C.c_double(1.0), None,
+                                                      C.c_int(0), C.c_double(1.0), C.c_double(20.0), C.c_int(0), p(de), p(dl), p(dc), p(di), s))
+        sel = torch.nonzero(dc == 0).flatten().to(torch.int32)          # stays on the device
+        cnt = torch.tensor([sel.numel()], dtype=torch.int32, device="cuda")
+        dsol = de.clone()                                               # converged shots keep the BP decision
+        L.check(L.lib().qldpc_osd0_batch_dev(g.handle, C.c_int64(B), p(ds), p(dl), p(de), None, p(sel), p(cnt), p(dsol), s))
+        L.check(L.lib().qldpc_gf2_spmv_batch_dev(g.handle, C.c_int64(B), p(dsol), p(dchk), s))
+        st.synchronize()
+    assert np.array_equal(dsol.cpu().numpy(), want)
+    assert np.array_equal(dchk.cpu().numpy(), synd)                     # every final answer reproduces its syndrome
+    # without a selection every shot is solved
+    with torch.cuda.stream(st):
+        dall = torch.empty_like(de)
+        L.check(L.lib().qldpc_osd0_batch_dev(g.handle, C.c_int64(B), p(ds), p(dl), p(de), None, None, None, p(dall), s))
+        st.synchronize()
+    b = int(np.flatnonzero(conv_o == 1)[0])
+    assert np.array_equal(dall.cpu().numpy()[b], oracle.osd0(ip, ix, n, synd[b], llr_o[b], err_o[b]))
