@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Randomised differential soak: GPU entry points vs the CPU checker on seeded random configurations for a time budget.
+  python tools/soak.py [--seconds 240] [--seed 1]      (exit code 1 and a repro line on the first mismatch)"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: F401,E402
+import qldpc_amd  # noqa: F401,E402
+from qldpc_amd import _lib as L  # noqa: E402
+from qldpc_amd.data import load_code, load_circuit_matrices  # noqa: E402
+from oracle import oracle  # noqa: E402  (checker)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=240)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+codes = {t: load_code(t) for t in ("bb72", "bb90", "bb108", "bb144", "bb288", "steane")}
+circ = {t: load_circuit_matrices(t) for t in ("circ72", "circ144")}
+graphs = {}
+
+
+def graph(key, ip, ix, n):
+    if key not in graphs:
+        graphs[key] = L.Graph(ip, ix, n)
+    return graphs[key]
+
+
+def fail(msg):
+    print("MISMATCH", msg, flush=True)
+    sys.exit(1)
+
+
+t_end = time.time() + a.seconds
+count = {"decode": 0, "tally": 0, "osd": 0, "circuit": 0}
+gold = {}
+for t in ("circ72",):
+    with np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", t + "_noise.npz")) as z:
+        gold[t] = {k: z[k] for k in z.files}
+cstate = {}
+
+
+def circuit_setup(tag):
+    if tag not in cstate:
+        g, d = gold[tag], circ[tag]
+        co = oracle.make_circuit(g, g["Lx"], g["Lz"])
+        secs, grs, prs, mks = [], [], [], []
+        for s2 in "ZX":
+            n2 = int(d[f"Hdec{s2}_shape"][1])
+            pr = oracle.prior_llrs(d[f"channel_probs{s2}"])
+            secs.append(oracle.make_sector(d[f"Hdec{s2}_indptr"], d[f"Hdec{s2}_indices"], n2, pr, d[f"H{s2}_logical_indptr"], d[f"H{s2}_logical_indices"]))
+            grs.append(L.Graph(d[f"Hdec{s2}_indptr"], d[f"Hdec{s2}_indices"], n2)); prs.append(pr)
+            mks.append(L.logical_column_masks((d[f"H{s2}_logical_indptr"], d[f"H{s2}_logical_indices"]), n2))
+        cstate[tag] = (g, co, secs, grs, prs, mks)
+    return cstate[tag]
+
+while time.time() < t_end:
+    kind = rng.choice(["decode", "decode", "tally", "osd", "circuit"])
+    if kind == "circuit":
+        g, co, secs, grs, prs, mks = circuit_setup("circ72")
+        p = float(rng.choice([0.001, 0.003, 0.005, 0.01])); iters = int(rng.integers(1, 45)); N = int(rng.integers(1, 120))
+        seed = int(rng.integers(0, 2 ** 62)); begin = int(rng.integers(0, 10 ** 8)); use_osd = bool(rng.random() < 0.85)
+        mode, alpha = [("dynamical", 1.0), ("alvarado", float(rng.uniform(0.4, 1.0)))][int(rng.integers(0, 2))]
+        plan = L.CircuitPlan(g, g["Lx"], g["Lz"], grs[0], grs[1], prs[0], prs[1], mks[0], mks[1], p, max_iter=iters, alpha_z=alpha, alpha_x=alpha,
+                             alpha_mode=mode, use_osd=use_osd, batch=int(rng.choice([16, 64, 4096])))
+        plan.run(seed, begin, N)
+        got = plan.read()
+        plan.close()
+        want = oracle.circuit_sample_decode_tally(co, secs[0], secs[1], p, seed, begin, N, max_iter=iters, alpha=alpha, alpha_mode=mode, use_osd=use_osd, threads=0)
+        if not np.array_equal(got, want):
+            fail(f"circuit p={p} iters={iters} N={N} seed={seed} begin={begin} osd={use_osd} mode={mode} alpha={alpha} got={got.tolist()} want={want.tolist()}")
+        count[kind] += 1
+        continue
+    if kind == "decode":
+        if rng.random() < 0.7:
+            tag = str(rng.choice(list(codes)))
+            c = codes[tag]; ip, ix, n = c["Hx_indptr"], c["Hx_indices"], int(c["n"])
+        else:
+            tag = str(rng.choice(list(circ))); s = str(rng.choice(["Z", "X"]))
+            d = circ[tag]; ip, ix, n = d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], int(d[f"Hdec{s}_shape"][1]); tag += s
+        g = graph(tag, ip, ix, n)
+        B = int(rng.integers(1, 300 if n < 1000 else 24))
+        p = float(rng.choice([0.002, 0.01, 0.04, 0.09]))
+        E = (rng.random((B, n)) < p).astype(np.int8)
+        synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+        prior = np.full(n, np.log((1 - p) / p)) + (rng.normal(0, 0.5, n) if rng.random() < 0.5 else 0.0)
+        if rng.random() < 0.15:
+            prior[rng.integers(0, n)] = rng.choice([0.0, -0.0, np.inf, -np.inf, np.nan])
+        mode, alpha = [("dynamical", 1.0), ("alvarado", float(rng.uniform(0.3, 1.1))), ("alvarado-autoregressive", rng.uniform(0.3, 1.0, int(rng.integers(1, 6))))][int(rng.integers(0, 3))]
+        damping = float(rng.choice([1.0, 1.0, 0.9, 0.5]))
+        clip = float(rng.choice([20.0, 5.0, 50.0]))
+        iters = int(rng.integers(1, 60))
+        flags = int(rng.choice([0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM, L.FLAG_KERNEL_GENERIC if n < 1000 else 0]))
+        env = rng.random() < 0.2 and n > 1000
+        if env:
+            os.environ["QLDPC_WG_VGLOBAL"] = "1"
+        try:
+            out = L.minsum_decode_batch(g, synd, prior, iters, mode, alpha, damping=damping, clip_llr=clip, flags=flags)
+        except L.QldpcError as e:
+            if "does not support" in str(e):
+                continue
+            raise
+        finally:
+            os.environ.pop("QLDPC_WG_VGLOBAL", None)
+        ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=iters, alpha=alpha, alpha_mode=mode, damping=damping, clip_llr=clip)
+        for nm, x, y in zip(("err", "conv", "llr", "iter"), (out[0], out[1].astype(bool), out[2], out[3]), (ref[0], ref[1].astype(bool), ref[2], ref[3])):
+            if not np.array_equal(x, y, equal_nan=True):
+                fail(f"decode {tag} B={B} p={p} mode={mode} alpha={alpha} damping={damping} clip={clip} iters={iters} flags={flags} vg={env} field={nm} seed={a.seed} n={count}")
+    elif kind == "tally":
+        tag = str(rng.choice(["bb72", "bb90", "bb108", "bb144", "bb288", "steane"]))
+        c = codes[tag]; ip, ix, n = c["Hx_indptr"], c["Hx_indices"], int(c["n"])
+        g = graph(tag, ip, ix, n)
+        p = float(rng.choice([0.003, 0.01, 0.03, 0.06]))
+        N = int(rng.integers(1, 8000)); begin = int(rng.integers(0, 10 ** 9)); seed = int(rng.integers(0, 2 ** 62))
+        iters = int(rng.integers(1, 55)); use_osd = bool(rng.random() < 0.8)
+        flags = int(rng.choice([0, L.FLAG_FIXED_ITERS, L.FLAG_MC_UNFUSED, L.FLAG_MC_UNFUSED | L.FLAG_KERNEL_STREAM]))
+        got = L.cc_sample_decode_tally(g, c["Lx"], p, seed, begin, N, max_iter=iters, use_osd=use_osd, flags=flags)
+        want = oracle.cc_sample_decode_tally(ip, ix, n, c["Lx"], p, seed, begin, N, max_iter=iters, use_osd=use_osd, threads=0)
+        if not np.array_equal(got, want):
+            fail(f"tally {tag} p={p} N={N} begin={begin} seed={seed} iters={iters} osd={use_osd} flags={flags} got={got.tolist()} want={want.tolist()}")
+    else:
+        import ctypes as C
+        tag = str(rng.choice(list(circ))); s = str(rng.choice(["Z", "X"]))
+        d = circ[tag]; ip, ix, n = d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], int(d[f"Hdec{s}_shape"][1])
+        g = graph(tag + s, ip, ix, n); m = len(ip) - 1
+        B = 3
+        E = (rng.random((B, n)) < 0.01).astype(np.int8)
+        synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+        if rng.random() < 0.3:
+            synd[0] = rng.random(m) < 0.5
+        llr = rng.normal(3, 4, (B, n))
+        if rng.random() < 0.5:
+            llr = np.round(llr)
+        hard = (rng.random((B, n)) < 0.01).astype(np.int8)
+        env = str(rng.choice(["", "QLDPC_OSD_UG", "QLDPC_OSD_GLOBAL"])) if tag == "circ72" else str(rng.choice(["", "QLDPC_OSD_UG"]))
+        if env:
+            os.environ[env] = "1"
+        sol = np.zeros((B, n), np.int8)
+        L.check(L.lib().qldpc_osd0_batch(g.handle, C.c_int64(B), L.ptr(synd, C.c_int8), L.ptr(llr, C.c_double), L.ptr(hard, C.c_int8), None, L.ptr(sol, C.c_int8)))
+        if env:
+            os.environ.pop(env)
+        for b in range(B):
+            if not np.array_equal(sol[b], oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b])):
+                fail(f"osd {tag}{s} env={env} b={b} seed={a.seed} n={count}")
+    count[kind] += 1
+print(f"soak ok: {count} cases in {a.seconds:.0f}s (seed {a.seed})", flush=True)
