@@ -48,7 +48,7 @@ int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     if (!want_stream && can_res)
         return minsum_resident_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
     if (!want_stream && wg_supported(g, damping))
-        return minsum_wg_launch(g, B, d_synd, d_prior, max_iter, d_alpha, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
+        return minsum_wg_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
     return minsum_stream_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
 }
 

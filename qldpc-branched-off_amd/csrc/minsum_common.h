@@ -57,7 +57,7 @@ int judge_failed_launch(const qldpc_graph *g, const int32_t *d_count, const uint
 // workgroup-per-shot kernel for large graphs (minsum_wg.hip)
 bool wg_supported(const qldpc_graph *g, double damping);
 int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
-                     double clip, int flags, bool clean, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
+                     double damping, double clip, int flags, bool clean, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
 // "clean" decoder inputs, verified on the host: every prior finite and not -0.0, clip finite > 0, every alpha finite > 0.
 // Then no message or posterior can be -0.0 and no |q| NaN, which the regular and lean kernels exploit (see their headers).
 bool inputs_clean(const double *prior, int n, double clip, const double *alpha, int n_alpha);

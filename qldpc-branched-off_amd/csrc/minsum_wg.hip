@@ -10,10 +10,11 @@
 //   variable pass: thread per column; index tables are ELL/slot-major in global memory, so a wave's index loads are
 //   contiguous.  The syndrome test of iteration k is a by-product of the sweep of iteration k+1; a workgroup that
 //   converged fetches its next shot (persistent grid), so per-shot early exit costs nothing.
-// damping != 1 needs Q_old per edge and is served by the streaming kernel instead.
+// damping != 1 needs Q_old per edge (245 KB per shot): it lives in a slot-major HBM/L2 slab per workgroup (DAMP variants).
 #include "common.h"
 #include "minsum_common.h"
 
+#include <cmath>
 #include <cstdlib>
 
 namespace qldpc {
@@ -28,13 +29,16 @@ struct WgArgs {
     double clip;
     int8_t *out_err; double *out_llr; uint8_t *out_conv; int32_t *out_iter;
     int offP, offI, offF;
+    double damping;
+    double *qold;          // DAMP kernels: Q_old per edge, slot-major [round_up(rdeg, 8)][m] per workgroup in HBM/L2 (kernels.py:336-345)
+    int qstride;           // doubles per workgroup in qold
     double *vglobal;       // VG kernels: posteriors V[n] per workgroup in HBM/L2 (graphs whose V does not fit next to the check states in LDS)
     int *queue;            // next shot to decode (zeroed before the launch): shots are handed out one at a time, so the
                            // workgroups finish together although their shots run 1..max_iter iterations
 };
 
 
-template <bool VG>
+template <bool VG, bool DAMP>
 __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
     extern __shared__ unsigned char lds[];
     double *V;
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
     unsigned long long *SI = reinterpret_cast<unsigned long long *>(lds + A.offI); // bits 0-55 input signs, 56-62 argmin (127 = none), 63 total sign
     int *unsat = reinterpret_cast<int *>(lds + A.offF);
     const int m = A.m, n = A.n, max_iter = A.max_iter, tid = threadIdx.x, T = blockDim.x;
-    const double clip = A.clip;
+    const double clip = A.clip, damping = A.damping, one_minus_d = 1.0 - A.damping;
+    double *Qo = DAMP ? A.qold + (size_t)blockIdx.x * A.qstride : nullptr;
 
     for (;;) {
         if (tid == 0) unsat[2] = atomicAdd(A.queue, 1);                                       // unsat[2]: the shot this workgroup decodes next
@@ -79,8 +84,10 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
                             const double mag = (k == argp) ? p2p : p1p;                      // kernels.py:313
                             const double r = (spp != (bool)((ip >> k) & 1)) ? -mag : mag;    // R_{it-1}[e], kernels.py:311-314
                             x = clip_nan(v - r, clip);                                       // kernels.py:325-333
-                            if (A.nfcheck && prior_not_finite(A.prior[col])) x = NAN;        // kernels.py:336 with Q_old = +-inf (see minsum_common.h)
+                            if (DAMP) x = clip_only(damping * x + one_minus_d * Qo[(size_t)k * m + i], clip);   // kernels.py:336-342
+                            else if (A.nfcheck && prior_not_finite(A.prior[col])) x = NAN;   // kernels.py:336 with Q_old = +-inf (see minsum_common.h)
                         }
+                        if (DAMP && it < max_iter) Qo[(size_t)k * m + i] = x;                // kernels.py:344-345 (iteration 0 stores the unclipped prior)
                         const bool neg = !(x >= 0.0);                                        // kernels.py:296-299
                         sp ^= neg;
                         negbits |= (unsigned long long)neg << k;
@@ -154,10 +161,11 @@ __device__ __forceinline__ double flip_sign(double x, uint32_t signword) { retur
 // One row of the check pass, edges taken 8 at a time: the 8 index loads (slot-major table, coalesced), then the 8 posterior
 // gathers from LDS are issued back to back before the dependent min/sign chain starts, so their latencies overlap instead
 // of adding up per edge (the per-edge loop the compiler emits otherwise waits for memory twice per edge).
-template <bool NANSEL, bool FIRST>
+template <bool NANSEL, bool FIRST, bool DAMP>
 __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int m, const double *__restrict__ V, int deg, double p1s, double p2s,
-                                            uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, bool &par, double &min1,
-                                            double &min2, int &arg, uint32_t &nlo, uint32_t &nhi) {
+                                            uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, double damping, double one_minus_d,
+                                            double *__restrict__ qo, bool store_q, bool &par, double &min1, double &min2, int &arg, uint32_t &nlo,
+                                            uint32_t &nhi) {
     for (int k0 = 0; k0 < deg; k0 += 8) {
         uint32_t c[8];
         double v[8];
@@ -165,6 +173,11 @@ __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int
         for (int u = 0; u < 8; u++) c[u] = ec[(size_t)(k0 + u) * m];                        // table rows are padded to a multiple of 8 with column 0
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = V[c[u]];
+        double qprev[8];
+        if (DAMP && !FIRST) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) qprev[u] = qo[(size_t)(k0 + u) * m];                 // slab rows are padded to a multiple of 8 slots
+        }
         const uint32_t pw = (k0 < 32) ? (ip_lo >> k0) : (ip_hi >> (k0 - 32));                // previous sign bits of this chunk
         const int au = argp - k0;
         uint32_t cb = 0u;
@@ -179,8 +192,11 @@ __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int
                     x = v[u] - r;                                                            // kernels.py:325
                     if (NANSEL) x = (x != x) ? 0.0 : x;                                      // kernels.py:328-329
                     x = wmax_s(wmin_s(x, clip), nclip);                                      // kernels.py:330-333
+                    if (DAMP) x = wmax_s(wmin_s(damping * x + one_minus_d * qprev[u], clip), nclip);   // kernels.py:336-342 (finite operands)
                 }
-                cb |= ((uint32_t)__double2hiint(x) >> 31) << u;                              // x is never -0.0 or NaN here (see above)
+                if (DAMP && store_q) qo[(size_t)(k0 + u) * m] = x;                           // kernels.py:344-345
+                // without damping x is never -0.0 or NaN here (see above); a damped x may underflow to -0.0, which counts as positive
+                cb |= (DAMP ? (x < 0.0 ? 1u : 0u) : ((uint32_t)__double2hiint(x) >> 31)) << u;
                 if (fabs(x) < min1) arg = k0 + u;                                            // kernels.py:301-304 (strict: first minimum wins)
                 min2 = wmin(min2, wmax_abs2(min1, x));                                       // kernels.py:302,305-306
                 min1 = wmin_abs2(min1, x);
@@ -190,7 +206,7 @@ __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int
     }
 }
 
-template <bool NANSEL, bool VG>
+template <bool NANSEL, bool VG, bool DAMP>
 __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     extern __shared__ unsigned char lds[];
     double *V;
@@ -199,7 +215,8 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     uint2 *SI = reinterpret_cast<uint2 *>(lds + A.offI);            // .x = sign bits 0-31, .y = sign bits 32-55 | argmin << 24; [m + 1]
     int *unsat = reinterpret_cast<int *>(lds + A.offF);
     const int m = A.m, n = A.n, max_iter = A.max_iter, tid = threadIdx.x, T = blockDim.x;
-    const double clip = A.clip, nclip = -A.clip;
+    const double clip = A.clip, nclip = -A.clip, damping = A.damping, one_minus_d = 1.0 - A.damping;
+    double *Qo = DAMP ? A.qold + (size_t)blockIdx.x * A.qstride : nullptr;
     const int deg_own = (tid < m) ? A.indptr[tid + 1] - A.indptr[tid] : 0;                   // the thread's first row, constant over shots
     if (tid == 0) { SP[m] = make_double2(0.0, 0.0); SI[m] = make_uint2(0u, 0u); }            // dummy check read by padded column slots
 
@@ -224,7 +241,8 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
                     int arg = 127;
                     uint32_t nlo = 0u, nhi = 0u;
                     if (it == 0) {
-                        wg_lean_row<NANSEL, true>(A.ell_col + i, m, V, deg, 0.0, 0.0, 0u, 0u, 127, clip, nclip, par, min1, min2, arg, nlo, nhi);
+                        wg_lean_row<NANSEL, true, DAMP>(A.ell_col + i, m, V, deg, 0.0, 0.0, 0u, 0u, 127, clip, nclip, damping, one_minus_d, DAMP ? Qo + i : nullptr,
+                                                        it < max_iter, par, min1, min2, arg, nlo, nhi);
                     } else {
                         double p1s = 0.0, p2s = 0.0;
                         uint32_t ip_lo = 0u, ip_hi = 0u;
@@ -233,7 +251,8 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
                             const double2 t = SP[i]; const uint2 u = SI[i];
                             p1s = t.x; p2s = t.y; argp = (int)(u.y >> 24); ip_lo = u.x; ip_hi = u.y & 0x00FFFFFFu;
                         }
-                        wg_lean_row<NANSEL, false>(A.ell_col + i, m, V, deg, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, par, min1, min2, arg, nlo, nhi);
+                        wg_lean_row<NANSEL, false, DAMP>(A.ell_col + i, m, V, deg, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, damping, one_minus_d,
+                                                         DAMP ? Qo + i : nullptr, it < max_iter, par, min1, min2, arg, nlo, nhi);
                     }
                     if (it >= 1 && !done && par) unsat[it & 1] = 1;                          // kernels.py:357-359
                     if (it < max_iter && deg > 0) {                                          // kernels.py:285-286
@@ -301,7 +320,8 @@ static size_t wg_lds_bytes(const qldpc_graph *g, bool vg, int &offP, int &offI, 
 
 // 0: not supported, 1: everything in LDS, 2: check states in LDS, posteriors in global memory
 static int wg_mode(const qldpc_graph *g, double damping) {
-    if (damping != 1.0 || !g->d_ell_col || !g->d_ell_var) return 0;
+    (void)damping;                      // damping != 1 keeps Q_old in an HBM/L2 slab
+    if (!g->d_ell_col || !g->d_ell_var) return 0;
     if (g->m <= 0 || g->n <= 0 || g->max_row_deg > 56) return 0;
     int a, b, c;
     if (wg_lds_bytes(g, false, a, b, c) <= 160 * 1024 && !getenv("QLDPC_WG_VGLOBAL")) return 1;
@@ -311,23 +331,15 @@ static int wg_mode(const qldpc_graph *g, double damping) {
 bool wg_supported(const qldpc_graph *g, double damping) { return wg_mode(g, damping) != 0; }
 
 int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
-                     double clip, int flags, bool clean, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
+                     double damping, double clip, int flags, bool clean, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
     WgArgs A;
     A.m = g->m; A.n = g->n; A.max_iter = max_iter; A.fixed = (flags & QLDPC_FLAG_FIXED_ITERS) ? 1 : 0;
     A.rdeg = g->max_row_deg; A.cdeg = g->max_col_deg; A.nfcheck = (flags & QLDPC_FLAG_INTERNAL_PRIOR_FINITE) ? 0 : 1;
     A.indptr = g->d_indptr; A.ell_col = g->d_ell_col; A.ell_var = g->d_ell_var;
     A.B = B; A.synd = d_synd; A.prior = d_prior; A.alpha = d_alpha; A.clip = clip;
     A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;
-    const bool vg = (wg_mode(g, 1.0) == 2);
+    const bool vg = (wg_mode(g, damping) == 2), damp = (damping != 1.0);
     const size_t lds = wg_lds_bytes(g, vg, A.offP, A.offI, A.offF);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void *kernels[] = {reinterpret_cast<const void *>(minsum_wg_kernel<false>), reinterpret_cast<const void *>(minsum_wg_kernel<true>),
-                                 reinterpret_cast<const void *>(minsum_wg_lean_kernel<true, false>), reinterpret_cast<const void *>(minsum_wg_lean_kernel<false, false>),
-                                 reinterpret_cast<const void *>(minsum_wg_lean_kernel<true, true>), reinterpret_cast<const void *>(minsum_wg_lean_kernel<false, true>)};
-        for (const void *k : kernels) QLDPC_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     bool has_deg1 = false;
     for (int i = 0; i < g->m; i++) has_deg1 = has_deg1 || (g->indptr[i + 1] - g->indptr[i] == 1);
     const int block = (g->m > 512 || g->n > 4096) ? 1024 : 512;
@@ -336,18 +348,33 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     if (rcq != QLDPC_OK) return rcq;
     QLDPC_HIP_TRY(hipMemsetAsync(g->ws_queue.p, 0, 16, stream));
     A.queue = g->ws_queue.as<int>();
-    A.vglobal = nullptr;
+    A.vglobal = nullptr; A.qold = nullptr; A.qstride = 0; A.damping = damping;
     if (vg) {
         if ((rcq = g->ws_vals.ensure((size_t)grid * g->n * 8)) != QLDPC_OK) return rcq;
         A.vglobal = g->ws_vals.as<double>();
     }
-    const bool lean = clean && !getenv("QLDPC_WG_GENERIC");
-    if (lean && has_deg1 && vg) hipLaunchKernelGGL((minsum_wg_lean_kernel<true, true>), dim3(grid), dim3(block), lds, stream, A);
-    else if (lean && has_deg1) hipLaunchKernelGGL((minsum_wg_lean_kernel<true, false>), dim3(grid), dim3(block), lds, stream, A);
-    else if (lean && vg) hipLaunchKernelGGL((minsum_wg_lean_kernel<false, true>), dim3(grid), dim3(block), lds, stream, A);
-    else if (lean) hipLaunchKernelGGL((minsum_wg_lean_kernel<false, false>), dim3(grid), dim3(block), lds, stream, A);
-    else if (vg) hipLaunchKernelGGL(minsum_wg_kernel<true>, dim3(grid), dim3(block), lds, stream, A);
-    else hipLaunchKernelGGL(minsum_wg_kernel<false>, dim3(grid), dim3(block), lds, stream, A);
+    if (damp) {
+        A.qstride = (int)round_up(std::max(g->max_row_deg, 1), 8) * g->m;
+        if ((rcq = g->ws_qold.ensure((size_t)grid * A.qstride * 8)) != QLDPC_OK) return rcq;
+        A.qold = g->ws_qold.as<double>();
+    }
+    const bool lean = clean && std::isfinite(damping) && !getenv("QLDPC_WG_GENERIC");
+    using K = void (*)(WgArgs);
+    // [lean][nansel][vg][damp]
+    static const K table[2][2][2][2] = {
+        {{{minsum_wg_kernel<false, false>, minsum_wg_kernel<false, true>}, {minsum_wg_kernel<true, false>, minsum_wg_kernel<true, true>}},
+         {{minsum_wg_kernel<false, false>, minsum_wg_kernel<false, true>}, {minsum_wg_kernel<true, false>, minsum_wg_kernel<true, true>}}},
+        {{{minsum_wg_lean_kernel<false, false, false>, minsum_wg_lean_kernel<false, false, true>},
+          {minsum_wg_lean_kernel<false, true, false>, minsum_wg_lean_kernel<false, true, true>}},
+         {{minsum_wg_lean_kernel<true, false, false>, minsum_wg_lean_kernel<true, false, true>},
+          {minsum_wg_lean_kernel<true, true, false>, minsum_wg_lean_kernel<true, true, true>}}}};
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (int a2 = 0; a2 < 2; a2++) for (int b2 = 0; b2 < 2; b2++) for (int c2 = 0; c2 < 2; c2++) for (int d2 = 0; d2 < 2; d2++)
+            QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(table[a2][b2][c2][d2]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(table[lean ? 1 : 0][has_deg1 ? 1 : 0][vg ? 1 : 0][damp ? 1 : 0], dim3(grid), dim3(block), lds, stream, A);
     QLDPC_HIP_TRY(hipGetLastError());
     return QLDPC_OK;
 }
