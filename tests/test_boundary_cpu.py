@@ -121,3 +121,38 @@ def test_cache_key_and_format(tmp_path):
     back = load_matrices(str(tmp_path), "abc")
     assert all(np.array_equal(back[k], M[k]) for k in M)
     assert load_matrices(str(tmp_path), "missing") is None
+
+
+def test_estimator_host_logic_without_gpu(oracle, golden):
+    """Host side of the alpha / beta estimators (decoding/_fit.py, alpha.py): fed with range + integer histograms computed from the
+    ORACLE's samples (what the device returns), it reproduces the factors the reference fitted (tests/golden/estimators.npz)."""
+    import numpy as np
+    from conftest import estimator_cases
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd.decoding.alpha import _alpha_from_stats
+    from qldpc_amd.simulation.engine import _estimation_trials
+
+    class HostStats:
+        def __init__(self, samples, bits):
+            fin = np.isfinite(samples)
+            self.s0, self.s1 = samples[fin & (bits == 0)], samples[fin & (bits == 1)]
+            self.finite = (self.s0.size, self.s1.size)
+            both = np.concatenate([self.s0, self.s1])
+            self.range = (float(both.min()), float(both.max()))
+
+        def histogram(self, edges):
+            return (np.histogram(self.s0, bins=edges)[0].astype(np.int64), np.histogram(self.s1, bins=edges)[0].astype(np.int64))
+
+    done = 0
+    for c in estimator_cases(golden("estimators")):
+        if c["kind"] != "alvarado":
+            continue
+        R = oracle.alpha_messages(c["indptr"], c["indices"], c["n"], c["errors"], c["prior"])
+        st = HostStats(R.ravel(), c["errors"][:, np.asarray(c["indices"])].ravel())
+        a, r2 = _alpha_from_stats(st, c["bins"])
+        assert abs(a - c["out"]["alpha"]) <= 1e-9 and abs(r2 - c["out"]["r2"]) <= 1e-9, c["name"]
+        done += 1
+    assert done == 3
+    # engine.py:230-246: dynamic number of estimation trials unless the caller changed the default of 5000
+    assert _estimation_trials(5000, 8785, 0.005) == 500 and _estimation_trials(5000, 144, 0.005) == 2777
+    assert _estimation_trials(5000, 10, 0.0001) == 50000 and _estimation_trials(1234, 8785, 0.005) == 1234
