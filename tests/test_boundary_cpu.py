@@ -156,3 +156,24 @@ def test_estimator_host_logic_without_gpu(oracle, golden):
     # engine.py:230-246: dynamic number of estimation trials unless the caller changed the default of 5000
     assert _estimation_trials(5000, 8785, 0.005) == 500 and _estimation_trials(5000, 144, 0.005) == 2777
     assert _estimation_trials(5000, 10, 0.0001) == 50000 and _estimation_trials(1234, 8785, 0.005) == 1234
+
+
+def test_circuit_generator_matches_reference_arrays(golden):
+    """Host logic, no GPU: BBCodeCircuit (arithmetic neighbour computation) + CompiledCircuit (table-driven lowering) reproduce the arrays the
+    REFERENCE's codes/bb_code.py + noise/compiled.py produced for [[72,12,6]] x 6 and [[144,12,12]] x 12 cycles (tests/golden/circ*_noise.npz)."""
+    import numpy as np
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd.data import load_code
+    from qldpc_amd.codes.bb_code import BBCodeCircuit
+    from qldpc_amd.noise.compiled import CompiledCircuit
+    for tag, code in (("circ72", "bb72"), ("circ144", "bb144")):
+        g = golden(tag + "_noise")
+        c = load_code(code)
+        cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=int(g["num_cycles"]), ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"],
+                           a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+        comp = CompiledCircuit(cb.get_full_circuit(), cb.cycle * 2, cb.lin_order, cb.data_qubits, cb.Xchecks, cb.Zchecks)
+        for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions", "x_syn_ptrs", "z_syn_positions", "z_syn_ptrs",
+                  "x_check_indices", "x_check_ptrs", "z_check_indices", "z_check_ptrs", "data_qubit_indices"):
+            assert np.array_equal(getattr(comp, k), g[k]), (tag, k)
+        for k in ("total_qubits", "num_error_locs", "max_circuit_size", "max_syndromes_x", "max_syndromes_z", "num_x_checks", "num_z_checks"):
+            assert int(getattr(comp, k)) == int(g[k]), (tag, k)
