@@ -84,7 +84,8 @@ int qldpc_graph_dims(const qldpc_graph *g, int *m, int *n, int *nnz);
 /* a1 + a2: minsum_decoder_full (src/decoding/kernels.py:234-366) and minsum_decoder_full_autoregressive
  * (kernels.py:369-485), batched over B independent syndromes.  B = 1 backs performMinSum_Symmetric_Sparse
  * (src/decoding/sparse.py:5-54).  Outputs per shot: candidateError int8[n], converged, values f64[n],
- * final_iter (max_iter-1 when not converged).  alpha_seq may be NULL unless alpha_mode == SEQ. */
+ * final_iter (max_iter-1 when not converged).  alpha_seq may be NULL unless alpha_mode == SEQ. * The host-pointer form accepts out_llr == NULL: the posteriors (8n of the 9n + 5 result bytes per shot) are then not copied back.
+ */
 int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *prior,
                               int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq, int alpha_len,
                               double damping, double clip_llr, int flags,

@@ -180,8 +180,9 @@ def graph_for(indptr, indices, n, device=0):
     return g
 
 
-def minsum_decode_batch(graph, syndromes, prior, max_iter, alpha_mode, alpha, damping=1.0, clip_llr=20.0, flags=0):
-    """qldpc_minsum_decode_batch on host arrays -> (err int8[B,n], conv uint8[B], llr f64[B,n], iters int32[B])."""
+def minsum_decode_batch(graph, syndromes, prior, max_iter, alpha_mode, alpha, damping=1.0, clip_llr=20.0, flags=0, want_llr=True):
+    """qldpc_minsum_decode_batch on host arrays -> (err int8[B,n], conv uint8[B], llr f64[B,n], iters int32[B]).
+    want_llr=False leaves the posteriors on the device (llr is returned as None): 9x fewer result bytes over PCIe."""
     mode, aval, seq = alpha_args(alpha_mode, alpha)
     syndromes = i8(syndromes).reshape(-1, graph.m) if graph.m else np.zeros((np.asarray(syndromes).shape[0], 0), np.int8)
     B = syndromes.shape[0]
@@ -189,13 +190,14 @@ def minsum_decode_batch(graph, syndromes, prior, max_iter, alpha_mode, alpha, da
     if prior.size != graph.n:
         raise ValueError(f"initialBelief has {prior.size} entries, H has {graph.n} columns")
     err = np.zeros((B, graph.n), np.int8)
-    llr = np.zeros((B, graph.n), np.float64)
+    llr = np.zeros((B, graph.n), np.float64) if want_llr else None
     conv = np.zeros(B, np.uint8)
     iters = np.zeros(B, np.int32)
     check(lib().qldpc_minsum_decode_batch(graph.handle, C.c_int64(B), ptr(syndromes, C.c_int8), ptr(prior, C.c_double),
                                           C.c_int(int(max_iter)), C.c_int(mode), C.c_double(aval), ptr(seq, C.c_double),
                                           C.c_int(seq.size), C.c_double(float(damping)), C.c_double(float(clip_llr)), C.c_int(flags),
-                                          ptr(err, C.c_int8), ptr(llr, C.c_double), ptr(conv, C.c_uint8), ptr(iters, C.c_int32)))
+                                          ptr(err, C.c_int8), ptr(llr, C.c_double) if want_llr else None, ptr(conv, C.c_uint8),
+                                          ptr(iters, C.c_int32)))
     return err, conv, llr, iters
 
 

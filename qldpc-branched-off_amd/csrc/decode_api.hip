@@ -109,7 +109,8 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, cons
                                            int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq,
                                            int alpha_len, double damping, double clip_llr, int flags, int8_t *out_err,
                                            double *out_llr, uint8_t *out_conv, int32_t *out_iter) {
-    int rc = check_decode_args(g, B, syndromes, prior, max_iter, clip_llr, out_err, out_llr, out_conv, out_iter);
+    // out_llr may be NULL: the posteriors (8n of the 9n + 5 result bytes per shot) then stay on the device
+    int rc = check_decode_args(g, B, syndromes, prior, max_iter, clip_llr, out_err, out_llr ? (const void *)out_llr : (const void *)out_err, out_conv, out_iter);
     if (rc != QLDPC_OK) return rc;
     if ((rc = use_device(g->device)) != QLDPC_OK) return rc;
     if (B == 0) return QLDPC_OK;
@@ -133,7 +134,7 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, cons
                          reinterpret_cast<int32_t *>(base + o_iter), nullptr);
     if (rc != QLDPC_OK) return rc;
     const size_t out_bytes = total - o_llr;
-    if (out_bytes <= ((size_t)1 << 20)) {
+    if (out_bytes <= ((size_t)1 << 20) && out_llr) {
         if (g->pin_cap < out_bytes) {
             if (g->pin) (void)hipHostFree(g->pin);
             g->pin = nullptr; g->pin_cap = 0;
@@ -148,7 +149,7 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, cons
         if (n) std::memcpy(out_err, h + (o_err - o_llr), B * n);
         std::memcpy(out_conv, h + (o_conv - o_llr), B);
     } else {
-        if (n) QLDPC_HIP_TRY(hipMemcpy(out_llr, base + o_llr, B * n * 8, hipMemcpyDeviceToHost));
+        if (n && out_llr) QLDPC_HIP_TRY(hipMemcpy(out_llr, base + o_llr, B * n * 8, hipMemcpyDeviceToHost));
         QLDPC_HIP_TRY(hipMemcpy(out_iter, base + o_iter, B * 4, hipMemcpyDeviceToHost));
         if (n) QLDPC_HIP_TRY(hipMemcpy(out_err, base + o_err, B * n, hipMemcpyDeviceToHost));
         QLDPC_HIP_TRY(hipMemcpy(out_conv, base + o_conv, B, hipMemcpyDeviceToHost));

@@ -492,6 +492,9 @@ def test_device_pointer_entry_point(L, oracle):
         st.synchronize()
     for a, b in zip((de.cpu().numpy(), dc.cpu().numpy(), dl.cpu().numpy(), di.cpu().numpy()), ref):
         assert np.array_equal(a, b, equal_nan=True)
+    # host-pointer form without the posteriors (out_llr == NULL): same decisions, 9x fewer result bytes over PCIe
+    e2, c2, l2, i2 = L.minsum_decode_batch(g, synd, prior, 20, "dynamical", 1.0, want_llr=False)
+    assert l2 is None and np.array_equal(e2, ref[0]) and np.array_equal(c2, ref[1]) and np.array_equal(i2, ref[3])
 
 
 def test_estimators_golden(L, golden):
