@@ -36,7 +36,7 @@ def fail(msg):
 
 
 t_end = time.time() + a.seconds
-count = {"decode": 0, "tally": 0, "osd": 0, "circuit": 0}
+count = {"decode": 0, "tally": 0, "osd": 0, "circuit": 0, "stats": 0, "osdw": 0}
 gold = {}
 for t in ("circ72",):
     with np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", t + "_noise.npz")) as z:
@@ -59,7 +59,58 @@ def circuit_setup(tag):
     return cstate[tag]
 
 while time.time() < t_end:
-    kind = rng.choice(["decode", "decode", "tally", "osd", "circuit"])
+    kind = rng.choice(["decode", "decode", "tally", "osd", "circuit", "stats", "osdw"])
+    if kind == "stats":                                   # estimator trial loops (f4): range, finite counts, both histograms
+        tag = str(rng.choice(["bb72", "bb144", "steane", "bb90"]))
+        c = codes[tag]; ip, ix, n = c["Hx_indptr"], c["Hx_indices"], int(c["n"])
+        g = graph(tag, ip, ix, n)
+        B = int(rng.integers(20, 400)); p = float(rng.choice([0.01, 0.04, 0.1]))
+        E = (rng.random((B, n)) < p).astype(np.int8)
+        prior = np.log((1 - p) / p) + rng.normal(0, 0.6, n)
+        bins = int(rng.integers(5, 80))
+        if rng.random() < 0.5:
+            prev = list(rng.uniform(0.4, 1.0, int(rng.integers(0, 5))))
+            damping = float(rng.choice([1.0, 0.8])); clip = float(rng.choice([20.0, 7.0]))
+            smp = oracle.alpha_messages(ip, ix, n, E, prior, alpha_prev=prev, damping=damping, clip_llr=clip).ravel()
+            bits = E[:, np.asarray(ix)].ravel()
+            st = L.MessageStats(g, E, prior, L.STATS_CHECK_MESSAGES, len(prev), alpha_mode="alvarado-autoregressive" if prev else "dynamical",
+                                alpha=np.array(prev) if prev else 1.0, damping=damping, clip_llr=clip)
+        else:
+            iters = int(rng.integers(1, 30))
+            smp = oracle.scopt_values(ip, ix, n, E, prior, max_iter=iters).ravel()
+            bits = E.ravel()
+            st = L.MessageStats(g, E, prior, L.STATS_POSTERIOR, iters)
+        fin = np.isfinite(smp)
+        ok = st.finite == (int((fin & (bits == 0)).sum()), int((fin & (bits == 1)).sum()))
+        if ok and fin.any():
+            ok = st.range == (smp[fin].min(), smp[fin].max())
+            edges = np.histogram_bin_edges(np.zeros(0), bins=bins, range=st.range)
+            h0, h1 = st.histogram(edges)
+            ok = ok and np.array_equal(h0, np.histogram(smp[fin & (bits == 0)], bins=bins, range=st.range)[0]) and \
+                np.array_equal(h1, np.histogram(smp[fin & (bits == 1)], bins=bins, range=st.range)[0])
+        st.close()
+        if not ok:
+            fail(f"stats {tag} B={B} p={p} bins={bins} seed={a.seed} n={count}")
+        count[kind] += 1
+        continue
+    if kind == "osdw":                                    # OSD-w sweep (f1) on small matrices with dependent rows
+        import ctypes as C
+        m2, n2 = int(rng.integers(3, 14)), int(rng.integers(6, 30))
+        Hd = (rng.random((m2, n2)) < 0.3).astype(np.int8)
+        if m2 > 3:
+            Hd[m2 // 2] = Hd[0] ^ Hd[1]
+        ip2, ix2, _ = L.canonical_csr(Hd)
+        g2 = L.Graph(ip2, ix2, n2)
+        synd = (rng.random(m2) < 0.5).astype(np.int8); llr = rng.normal(0, 3, n2); hard = (rng.random(n2) < 0.15).astype(np.int8)
+        order = int(rng.integers(1, 5)); maxc = int(rng.choice([0, 0, 3, 17]))
+        sol = np.zeros((1, n2), np.int8)
+        L.check(L.lib().qldpc_osdw_batch(g2.handle, C.c_int64(1), L.ptr(synd.reshape(1, -1), C.c_int8), L.ptr(llr.reshape(1, -1), C.c_double),
+                                         L.ptr(hard.reshape(1, -1), C.c_int8), None, C.c_int(order), C.c_int64(maxc), L.ptr(sol, C.c_int8)))
+        want = oracle.osdw(ip2, ix2, n2, synd, llr, hard, order, maxc or None)
+        if not np.array_equal(sol[0], want):
+            fail(f"osdw m={m2} n={n2} order={order} maxc={maxc} seed={a.seed} n={count}")
+        count[kind] += 1
+        continue
     if kind == "circuit":
         g, co, secs, grs, prs, mks = circuit_setup("circ72")
         p = float(rng.choice([0.001, 0.003, 0.005, 0.01])); iters = int(rng.integers(1, 45)); N = int(rng.integers(1, 120))
