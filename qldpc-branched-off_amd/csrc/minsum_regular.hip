@@ -81,7 +81,9 @@ template <> __device__ __forceinline__ double min_tree<6>(const double *a) { ret
 #define QLDPC_LB_T 512
 #define QLDPC_LB_W 8
 #endif
-template <int CDEG, int VDEG, bool DAMP, bool NANFREE, bool MC>
+// FIXED (all max_iter iterations executed for every shot, outputs frozen at convergence) is a template parameter: the fixed-work and the
+// early-exit forms are distinct kernel symbols, so a rocprofv3 --stats summary lists them separately.
+template <int CDEG, int VDEG, bool DAMP, bool NANFREE, bool MC, bool FIXED>
 __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(RegArgs A) {
     extern __shared__ unsigned char lds[];
     constexpr int RST = (CDEG % 2 == 0) ? CDEG + 1 : CDEG;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
 
         for (int it = 0; it <= max_iter; it++) {
             // ======== check phase: syndrome test of values_{it-1}, then R_it from Q_{it-1} ========
-            if ((A.fixed ? valid : !done) && has_check) {
+            if ((FIXED ? valid : !done) && has_check) {
                 double x[CDEG];
                 bool par = csyn;
 #pragma unroll
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
                 }
             }
             if (in_team && member == 0) unsat[(it + 1) & 1] = 0;
-            if (it < max_iter && (A.fixed ? valid : !done)) {
+            if (it < max_iter && (FIXED ? valid : !done)) {
 #pragma unroll
                 for (int v = 0; v < 2; v++)
                     if (has_var[v]) {
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
                     }
             }
             __syncthreads();
-            if (!A.fixed && active[0] == 0) break;
+            if (!FIXED && active[0] == 0) break;
         }
         __syncthreads();
         if (MC) {
@@ -398,18 +400,24 @@ bool regular_supported(const qldpc_graph *g, double clip, int max_iter) {
     return clip >= 0.0 && plan_regular(g, max_iter, P);
 }
 
-template <int CDEG, int VDEG, bool MC>
-static int launch_reg(const RegArgs &A, bool damp, bool nanfree, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
+template <int CDEG, int VDEG, bool MC, bool FIXED>
+static int launch_reg2(const RegArgs &A, bool damp, bool nanfree, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
     if (damp) {
         if (MC) return QLDPC_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((minsum_regular_kernel<CDEG, VDEG, true, false, false>), dim3(grid), dim3(block), lds, stream, A);
+        hipLaunchKernelGGL((minsum_regular_kernel<CDEG, VDEG, true, false, false, FIXED>), dim3(grid), dim3(block), lds, stream, A);
     } else if (nanfree) {
-        hipLaunchKernelGGL((minsum_regular_kernel<CDEG, VDEG, false, true, MC>), dim3(grid), dim3(block), lds, stream, A);
+        hipLaunchKernelGGL((minsum_regular_kernel<CDEG, VDEG, false, true, MC, FIXED>), dim3(grid), dim3(block), lds, stream, A);
     } else {
-        hipLaunchKernelGGL((minsum_regular_kernel<CDEG, VDEG, false, false, MC>), dim3(grid), dim3(block), lds, stream, A);
+        hipLaunchKernelGGL((minsum_regular_kernel<CDEG, VDEG, false, false, MC, FIXED>), dim3(grid), dim3(block), lds, stream, A);
     }
     QLDPC_HIP_TRY(hipGetLastError());
     return QLDPC_OK;
+}
+
+template <int CDEG, int VDEG, bool MC>
+static int launch_reg(const RegArgs &A, bool damp, bool nanfree, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
+    return A.fixed ? launch_reg2<CDEG, VDEG, MC, true>(A, damp, nanfree, grid, block, lds, stream)
+                   : launch_reg2<CDEG, VDEG, MC, false>(A, damp, nanfree, grid, block, lds, stream);
 }
 
 template <bool MC>
