@@ -36,6 +36,7 @@ def fail(msg):
 
 
 t_end = time.time() + a.seconds
+t_note = time.time() + 60
 count = {"decode": 0, "tally": 0, "osd": 0, "circuit": 0, "stats": 0, "osdw": 0}
 gold = {}
 for t in ("circ72",):
@@ -59,6 +60,9 @@ def circuit_setup(tag):
     return cstate[tag]
 
 while time.time() < t_end:
+    if time.time() > t_note:
+        print(f"  ... {count}", flush=True)          # progress line (a silent GPU job is taken to be hung)
+        t_note = time.time() + 60
     kind = rng.choice(["decode", "decode", "tally", "osd", "circuit", "stats", "osdw"])
     if kind == "stats":                                   # estimator trial loops (f4): range, finite counts, both histograms
         tag = str(rng.choice(["bb72", "bb144", "steane", "bb90"]))
