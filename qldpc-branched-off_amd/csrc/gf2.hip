@@ -779,6 +779,34 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 colrows[t] = (k < P.colptr[j + 1]) ? (uint16_t)P.rowidx[k] : (uint16_t)m;          // row m of U is all zero
             }
             __syncthreads();
+            // drops every still-alive column of the chunk from c0 on that is dependent on the pivots found so far (one thread per column)
+            auto kill_pass = [&](int c0) {
+                const int wq = row >> 6;
+                for (int c2 = c0 + tid; c2 < L; c2 += T) {
+                    if (!alive[c2]) continue;
+                    const uint16_t *cr2 = colrows + c2 * cd;
+                    int rr[8];                                           // the column's support once (cd <= 8; short columns point at the zero row m)
+#pragma unroll
+                    for (int d = 0; d < 8; d++) rr[d] = (d < cd) ? (int)cr2[d] : m;
+                    unsigned long long any = 0ull;
+                    for (int w = wq; w < mw; w++) {
+                        unsigned long long xs[8];
+#pragma unroll
+                        for (int d = 0; d < 8; d++) xs[d] = U[uswz(rr[d], w, mw)];
+                        unsigned long long x = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
+                        for (int d = 8; d < cd; d++) x ^= U[uswz(cr2[d], w, mw)];     // columns heavier than 8 (not the circuit-level matrices)
+                        any |= (w == wq) ? (x & (~0ull << (row & 63))) : x;
+                    }
+                    if (!any) alive[c2] = 0;
+                }
+            };
+            if (row > 0 && !P.nokill) {                                      // a fresh chunk late in the sweep is mostly dependent columns: one pass up
+                long long tk = clock64();                                    // front instead of one serial pivot step per dependent column
+                d_kills++;
+                kill_pass(0);
+                __syncthreads();
+                c_kill += clock64() - tk;
+            }
             // ================= blocks of up to kOsdBlock alive columns =================
             while (true) {
                 if (tid < 64) {                                              // wave 0 collects the next alive columns of the chunk (ballot scan)
@@ -925,25 +953,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 // ---- dependent columns were met: drop every column of the chunk that is dependent by now ----
                 if (anydep && !P.nokill) {
                     d_kills++;
-                    const int c0 = blk[3];
-                    const int wq = row >> 6;
-                    for (int c2 = c0 + tid; c2 < L; c2 += T) {
-                        if (!alive[c2]) continue;
-                        const uint16_t *cr2 = colrows + c2 * cd;
-                        int rr[8];                                           // the column's support once (cd <= 8; short columns point at the zero row m)
-#pragma unroll
-                        for (int d = 0; d < 8; d++) rr[d] = (d < cd) ? (int)cr2[d] : m;
-                        unsigned long long any = 0ull;
-                        for (int w = wq; w < mw; w++) {
-                            unsigned long long xs[8];
-#pragma unroll
-                            for (int d = 0; d < 8; d++) xs[d] = U[uswz(rr[d], w, mw)];
-                            unsigned long long x = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
-                            for (int d = 8; d < cd; d++) x ^= U[uswz(cr2[d], w, mw)];     // columns heavier than 8 (not the circuit-level matrices)
-                            any |= (w == wq) ? (x & (~0ull << (row & 63))) : x;
-                        }
-                        if (!any) alive[c2] = 0;
-                    }
+                    kill_pass(blk[3]);
                     __syncthreads();
                     c_kill += clock64() - tp;
                 }
