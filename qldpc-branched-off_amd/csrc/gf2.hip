@@ -656,7 +656,7 @@ struct OsdLdsArgs {
     unsigned long long *ugkeys;
     int *queue;                    // next list entry to process (zeroed before the launch): work is handed out one shot at a time
     unsigned long long *dbg;       // optional counters: [0] shots, [1] chunks, [2] columns swept, [3] pivots, [4] cycles, [5] kill passes, [6] blocks
-    int offIdx, offAlive, offRows, offPc, offR, offBlk, offMisc;
+    int offIdx, offAlive, offRows, offPc, offR, offBlk, offMisc, offSort;
 };
 
 #ifndef QLDPC_OSD_BLOCK
@@ -712,42 +712,118 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         const long long t_start = clock64();
         // ---- column order: ascending |llr| (osd.py:11-12), ties by ascending index; bitonic sort of (key, index) in LDS ----
         if (!P.ordering) {
-            // (key, index) pairs sorted IN PLACE (regular, conflict-free addresses; four independent compare-exchanges per thread in
-            // flight).  Network: bitonic merges that are ascending everywhere (first step of a merge pairs i with its mirror
-            // i ^ (size-1)), so the virtual +inf padding at positions >= n never moves and needs no storage.
+            // Stable LSD radix sort of the column indices by the 64-bit key, 8 passes of 8 bits (a bitonic network of (key, index)
+            // pairs cost 0.44 M cycles per shot, all of it compare-exchange instructions).  The keys stay where they are; a pass
+            // permutes the index array only.  Stability -- which is what makes ties come out in ascending index order, the
+            // permutation starting as the identity -- comes from (a) every wave owning a contiguous range of positions and walking it
+            // in order, (b) a lane's rank among the lanes of its step with the same digit (8 ballots), (c) an exclusive scan of the
+            // [digit][wave] counters in digit-major order.
             unsigned long long *keys;                                                               // [n]   (LDS: aliases U)
-            uint16_t *perm;                                                                         // [n]
-            if (UG) { keys = P.ugkeys + (size_t)blockIdx.x * (size_t)(n + (n + 3) / 4); perm = reinterpret_cast<uint16_t *>(keys + n); }
-            else { keys = reinterpret_cast<unsigned long long *>(lds); perm = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8); }
-            const int half = P.npad >> 1;
-            for (int j = tid; j < n; j += T) { keys[j] = osd_key(llr[j]); perm[j] = (uint16_t)j; }
-            __syncthreads();
-            for (int size = 2; size <= P.npad; size <<= 1)
-                for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    const bool mirror = (stride == (size >> 1));
-                    for (int t0 = tid; t0 < half; t0 += 4 * T) {
-                        int ii[4], pq[4];
-                        bool ok[4];
-                        unsigned long long ka[4], kb[4];
-                        uint16_t ia[4], ib[4];
+            uint16_t *pa, *pb;                                                                      // [n] each
+            unsigned *cnt;                                                                          // [256][NW] + [NW]
+            const int NW = T >> 6, wv = tid >> 6, lane = tid & 63;
+            if (UG) {
+                keys = P.ugkeys + (size_t)blockIdx.x * (size_t)(n + (n + 1) / 2);
+                pa = reinterpret_cast<uint16_t *>(keys + n); pb = pa + n;
+                cnt = reinterpret_cast<unsigned *>(lds + P.offSort);
+            } else {
+                keys = reinterpret_cast<unsigned long long *>(lds);
+                pa = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8); pb = pa + n;
+                cnt = reinterpret_cast<unsigned *>(lds + (((size_t)n * 12 + 15) & ~(size_t)15));
+            }
+            unsigned *wsum = cnt + 256 * NW;
+            const int span = (((n + NW - 1) / NW) + 63) & ~63;                                      // positions per wave, a multiple of 64
+            const int wbeg = wv * span, wend = min(n, wbeg + span);
+            for (int j = tid; j < n; j += T) { keys[j] = osd_key(llr[j]); pa[j] = (uint16_t)j; }
+            for (int pass = 0; pass < 8; pass++) {
+                const int shift = 8 * pass;
+                for (int e = tid; e < 256 * NW; e += T) cnt[e] = 0u;
+                __syncthreads();
+                constexpr int kSteps = 10;                                                          // steps of 64 positions kept in registers
+                const bool cached = (span <= 64 * kSteps);
+                int cj[kSteps];
+                unsigned cd[kSteps];
+                unsigned long long csame[kSteps];
+                if (cached) {                                                                       // all index / key loads of the pass in flight at once
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int t = t0 + u * T, lo = t & (stride - 1), i = ((t - lo) << 1) | lo;
-                            const int p2 = mirror ? (i ^ (size - 1)) : (i | stride);
-                            ok[u] = (t < half) && (p2 < n);                                       // i < p2; a partner in the padding is +inf: no exchange
-                            ii[u] = ok[u] ? i : 0; pq[u] = ok[u] ? p2 : 0;
+                    for (int st = 0; st < kSteps; st++) { const int pos = wbeg + 64 * st + lane; cj[st] = (pos < wend) ? (int)pa[pos] : 0; }
+#pragma unroll
+                    for (int st = 0; st < kSteps; st++) {
+                        const int pos = wbeg + 64 * st + lane;
+                        cd[st] = (pos < wend) ? (unsigned)((keys[cj[st]] >> shift) & 255ull) : 0u;
+                    }
+#pragma unroll
+                    for (int st = 0; st < kSteps; st++) {
+                        const bool valid = (wbeg + 64 * st + lane) < wend;
+                        unsigned long long same = __ballot(valid);                                  // lanes of this step holding the same digit
+#pragma unroll
+                        for (int b2 = 0; b2 < 8; b2++) {
+                            const unsigned long long bal = __ballot((cd[st] >> b2) & 1u);
+                            same &= ((cd[st] >> b2) & 1u) ? bal : ~bal;
                         }
+                        csame[st] = valid ? same : 0ull;
+                    }
+                }
+                for (int round = 0; round < 2; round++) {                                           // 0: count, 1: scatter
+                    if (cached) {
 #pragma unroll
-                        for (int u = 0; u < 4; u++) { ka[u] = keys[ii[u]]; kb[u] = keys[pq[u]]; ia[u] = perm[ii[u]]; ib[u] = perm[pq[u]]; }
-#pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            if (ok[u] && ((ka[u] > kb[u]) || (ka[u] == kb[u] && ia[u] > ib[u]))) {
-                                keys[ii[u]] = kb[u]; keys[pq[u]] = ka[u]; perm[ii[u]] = ib[u]; perm[pq[u]] = ia[u];
+                        for (int st = 0; st < kSteps; st++) {
+                            if (csame[st] != 0ull) {
+                                const int rank = __builtin_popcountll(csame[st] & ((1ull << lane) - 1ull)), tot = __builtin_popcountll(csame[st]);
+                                unsigned *slot = cnt + cd[st] * NW + wv;
+                                if (round == 0) {
+                                    if (rank == 0) *slot += (unsigned)tot;                          // one leader per digit; the column [.][wv] is this wave's own
+                                } else {
+                                    const unsigned base = *slot;                                    // read by the whole group before its leader advances it
+                                    pb[base + rank] = (uint16_t)cj[st];
+                                    if (rank == 0) *slot = base + (unsigned)tot;
+                                }
                             }
+                        }
+                    } else
+                    for (int p0 = wbeg; p0 < wend; p0 += 64) {
+                        const int pos = p0 + lane;
+                        const bool valid = pos < wend;
+                        const int j = valid ? (int)pa[pos] : 0;
+                        const unsigned d = valid ? (unsigned)((keys[j] >> shift) & 255ull) : 0u;
+                        unsigned long long same = __ballot(valid);
+#pragma unroll
+                        for (int b2 = 0; b2 < 8; b2++) {
+                            const unsigned long long bal = __ballot((d >> b2) & 1u);
+                            same &= ((d >> b2) & 1u) ? bal : ~bal;
+                        }
+                        if (valid) {
+                            const int rank = __builtin_popcountll(same & ((1ull << lane) - 1ull)), tot = __builtin_popcountll(same);
+                            unsigned *slot = cnt + d * NW + wv;
+                            if (round == 0) {
+                                if (rank == 0) *slot += (unsigned)tot;
+                            } else {
+                                const unsigned base = *slot;
+                                pb[base + rank] = (uint16_t)j;
+                                if (rank == 0) *slot = base + (unsigned)tot;
+                            }
+                        }
                     }
                     __syncthreads();
+                    if (round == 0) {                                                               // exclusive scan over (digit, wave), 4 entries per thread
+                        unsigned v[4], sum = 0u;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { v[e] = cnt[4 * tid + e]; sum += v[e]; }
+                        unsigned inc = sum;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+                        if (lane == 63) wsum[wv] = inc;
+                        __syncthreads();
+                        unsigned before = inc - sum;
+                        for (int w2 = 0; w2 < wv; w2++) before += wsum[w2];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { cnt[4 * tid + e] = before; before += v[e]; }
+                        __syncthreads();
+                    }
                 }
-            for (int j = tid; j < n; j += T) ordw[j] = perm[j];
+                uint16_t *tsw = pa; pa = pb; pb = tsw;
+            }
+            for (int j = tid; j < n; j += T) ordw[j] = pa[j];
             __syncthreads();
         }
         // ---- init: T = I (positions = original rows), b = s + H hard (osd.py:8-9) ----
@@ -1007,7 +1083,8 @@ static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
     P.npad = 1;
     while (P.npad < g->n) P.npad <<= 1;
     for (int mode = (g->m <= 1024 && !getenv("QLDPC_OSD_UG")) ? 1 : 2; mode <= 2; mode++) {
-        size_t off = (mode == 1) ? std::max((size_t)(g->m + 2) * P.mw * 8, (size_t)g->n * 10 + 16) : 0;     // U, aliased by the sort scratch (keys + indices)
+        const size_t sort_cnt = (size_t)256 * 16 * 4 + 16 * 4 + 64;                         // [256][waves] radix counters + per-wave sums
+        size_t off = (mode == 1) ? std::max((size_t)(g->m + 2) * P.mw * 8, (size_t)g->n * 12 + 16 + sort_cnt) : 0;     // U, aliased by the sort scratch
         off = (size_t)round_up((int64_t)off, 16);
         P.offIdx = (int)off; off += (size_t)P.K * 2;
         P.offAlive = (int)off; off += (size_t)P.K;
@@ -1016,6 +1093,7 @@ static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
         P.offR = (int)off; off += (size_t)kOsdBlock * P.mw * 8;
         P.offBlk = (int)off; off += (4 + 6 * kOsdBlock + 4) * 4;
         P.offMisc = (int)off; off += 64;
+        P.offSort = (int)off; off += (mode == 2) ? sort_cnt : 0;
         lds = off + 16;
         if (lds <= 160 * 1024) return mode;
     }
@@ -1034,7 +1112,7 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     const int grid = 512;
     const size_t sz_ord = (size_t)round_up((int64_t)grid * g->n * 2 + 64, 16);
     const size_t sz_u = (mode == 2) ? (size_t)grid * (size_t)(g->m + 2) * P.mw * 8 : 0;
-    const size_t per_keys = (size_t)g->n + (size_t)(g->n + 3) / 4;                       // u64 units: n keys + n u16 indices
+    const size_t per_keys = (size_t)g->n + (size_t)(g->n + 1) / 2;                       // u64 units: n keys + 2 x n u16 indices
     const size_t sz_k = (mode == 2) ? (size_t)grid * per_keys * 8 : 0;
     int rc = g->ws_misc.ensure(sz_ord + sz_u + sz_k);
     if (rc != QLDPC_OK) return rc;
