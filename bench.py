@@ -181,9 +181,26 @@ def main():
         t_gpu = _lib.cc_sample_decode_tally(graph, code["Lx"], args.p, SEED, 0, sample, max_iter=args.max_iter, flags=kflag)
         if not np.array_equal(t_cpu, t_gpu):
             raise SystemExit(f"GPU tally != oracle tally on the CPU sample: {t_gpu.tolist()} vs {t_cpu.tolist()}")
+        # one host thread on a smaller sample (SURVEY 8d asks for both figures)
+        one = int(max(20000, min(sample, rate / max(cores, 1) * 3.0)))
+        t0 = time.perf_counter()
+        orc.cc_sample_decode_tally(code["Hx_indptr"], code["Hx_indices"], n, code["Lx"], args.p, SEED, 0, one, max_iter=args.max_iter, threads=1)
+        dt_one = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(sample / dt_cpu, 1), "unit": "shots/s", "cores": cores, "kind": "port",
                                "sample": f"first {sample} shots of the same Philox stream (seed {SEED}), reference early-exit semantics, "
-                                         f"OpenMP over shots on {cores} threads; tally identical to the GPU's"}
+                                         f"OpenMP over shots on {cores} threads; tally identical to the GPU's",
+                               "single_thread": {"value": round(one / dt_one, 1), "unit": "shots/s", "sample": f"first {one} shots, 1 thread"}}
+        # LLR check of the north-star contract on a prefix: decode the syndromes of the first 4096 shots on both sides
+        from oracle import oracle as _o
+        E = np.stack([_o.cc_sample_errors(SEED, i, n, args.p) for i in range(4096)]).astype(np.int8)
+        synd = np.stack([_o.syndrome_check(code["Hx_indptr"], code["Hx_indices"], e) for e in E])
+        prior = np.full(n, np.log((1.0 - args.p) / args.p))
+        g_err, g_conv, g_llr, g_it = _lib.minsum_decode_batch(graph, synd, prior, args.max_iter, "dynamical", 1.0, flags=kflag)
+        c_err, c_conv, c_llr, c_it = _o.minsum_decode_batch(code["Hx_indptr"], code["Hx_indices"], n, synd, prior, max_iter=args.max_iter, threads=0)
+        diff = float(np.max(np.abs(g_llr - c_llr))) if g_llr.size else 0.0
+        if diff > 1e-5 or not (np.array_equal(g_err, c_err) and np.array_equal(g_it, c_it)):
+            raise SystemExit(f"LLR check failed: max |llr_gpu - llr_cpu| = {diff}")
+        out["llr_check"] = {"shots": 4096, "max_abs_diff": diff, "tolerance": 1e-5, "hard_decisions_and_iterations_identical": True}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
