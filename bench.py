@@ -163,6 +163,13 @@ def main():
     }
     if args.legs == "fixed":
         del out["reference_semantics"]
+    if args.code == "bb144" and args.kernel == "auto" and ms_fixed > 0:
+        # The messages are on-chip, so the binding resource is VALU issue, not HBM: 105.3 VALU wave-instructions per shot-iteration
+        # (SQ_INSTS_VALU, profiles/r01_f_pmc_regular.txt) against 256 CUs x 4 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz.
+        wi = 105.3 * B * args.max_iter * nl_fixed / (ms_fixed * 1e-3)
+        out["on_chip_bound"] = {"resource": "VALU issue", "achieved": round(wi / 1e9, 1), "peak": round(256 * 4 * 2.4e9 / 4 / 1e9, 1),
+                                "unit": "G wave-instructions/s", "frac": round(wi / (256 * 4 * 2.4e9 / 4), 3),
+                                "basis": "105.3 VALU wave-instructions per shot-iteration measured with rocprofv3 --pmc SQ_INSTS_VALU (profiles/r01_f_pmc_regular.txt)"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc          # the checker / CPU baseline, never the product path
