@@ -12,8 +12,14 @@
  *     (thread-local).  Kernels never "raise": non-convergence is an output value, as in the reference.
  *   - the caller owns every buffer; the library owns only opaque handles and its device workspaces.
  *   - *_dev variants take DEVICE pointers (hipMalloc'ed or torch CUDA tensors' data_ptr()) and a
- *     hipStream_t passed as void* (NULL = default stream); they enqueue work and do not synchronise.
+ *     hipStream_t passed as void* (NULL = default stream); they enqueue work and do not synchronise
+ *     (alpha tables are cached per graph handle: a schedule is uploaded the first time it is seen, asynchronously).
  *     The variants without _dev take HOST pointers, copy in/out and return when results are ready.
+ *   - every entry point selects its handle's device for the duration of the call and restores the caller's
+ *     current device before returning.
+ *   - a graph handle owns device workspaces shared by every decode / OSD call on it; calls on different streams
+ *     are ordered through an event (the later one waits for the earlier one's kernels), so concurrent streams are
+ *     safe but serialise per graph handle.  Use one handle per stream for real concurrency.
  *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
  *     QLDPC_ERR_NO_DEVICE.
  *   - matrices over GF(2) are CSR with sorted column indices (int32 indptr[m+1], indices[nnz]).
@@ -48,6 +54,15 @@ extern "C" {
 #define QLDPC_FLAG_KERNEL_RESIDENT 0x20 /* force the LDS/register-resident kernels (small graphs only) */
 #define QLDPC_FLAG_KERNEL_GENERIC 0x40  /* resident family: use the generic (irregular-degree) kernel even for regular graphs */
 #define QLDPC_FLAG_MC_UNFUSED 0x80      /* Monte-Carlo plans: separate sample / decode / judge launches instead of the fused kernel */
+/* kernel-variant selectors (parity tests and measurements; results are identical whichever is chosen) */
+#define QLDPC_FLAG_WG_VGLOBAL 0x100     /* workgroup-per-shot decoder: posteriors in HBM/L2 even when they fit LDS (the large-graph form) */
+#define QLDPC_FLAG_WG_GENERIC 0x200     /* workgroup-per-shot decoder: the any-input kernel even for host-verified clean inputs */
+#define QLDPC_FLAG_OSD_UG 0x400         /* OSD-0: row transform in HBM/L2 even when it fits LDS (the m > 1024 form) */
+#define QLDPC_FLAG_OSD_GLOBAL 0x800     /* OSD-0: the literal global-memory elimination (general fallback) */
+#define QLDPC_FLAG_OSD_NOKILL 0x1000    /* OSD-0: no parallel dependent-column tests */
+#define QLDPC_FLAG_OSD_LEGACY 0x2000    /* OSD-0: the round-1 Gauss-Jordan LDS kernel instead of the forward-elimination kernel */
+#define QLDPC_FLAG_CLOCK_PROBE 0x4000   /* plans: workgroups stamp s_memtime / s_memrealtime around their work (see *_plan_clock) */
+#define QLDPC_FLAG_WG_ROWMAJOR 0x8000   /* workgroup-per-shot decoder: natural row / column order instead of the degree-sorted assignment */
 
 /* tally slots written by the *_sample_decode_tally entry points (int64[QLDPC_TALLY_SLOTS]);
  * replaces the Python tally loop of src/simulation/engine.py:450-457 */
@@ -124,12 +139,16 @@ int qldpc_gf2_eliminate_packed(int64_t B, int m, int n, int nwords, uint64_t *A,
  * ordering (int32[B][n], may be NULL): column order to eliminate in; NULL = ascending |llr| with ties broken by
  * ascending index (np.argsort's default kind leaves ties implementation-defined, osd.py:12). solution int8[B][n]. */
 int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *llr, const int8_t *hard,
-                     const int32_t *ordering, int8_t *solution);
+                     const int32_t *ordering, int flags, int8_t *solution);
 /* same on device pointers; only enqueues on `stream`.  d_select / d_select_count (both NULL = all B shots): device list of the shots to
  * solve and its device-resident length, e.g. the shots qldpc_minsum_decode_batch_dev left unconverged -- the decode -> OSD-0 hand-over of
  * src/simulation/engine.py:96-97 without a host round trip.  Shots not listed keep whatever d_solution holds. */
 int qldpc_osd0_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_syndromes, const double *d_llr, const int8_t *d_hard,
-                         const int32_t *d_ordering, const int32_t *d_select, const int32_t *d_select_count, int8_t *d_solution, void *stream);
+                         const int32_t *d_ordering, const int32_t *d_select, const int32_t *d_select_count, int flags, int8_t *d_solution,
+                         void *stream);
+/* Phase counters of the OSD-0 kernels on the current device (uint64[16]; layout in csrc/osd_common.h).  Only the diagnostic build
+ * (make -C csrc timers) counts; the product build carries no clock reads and returns QLDPC_ERR_UNSUPPORTED. */
+int qldpc_osd_timers_read(uint64_t *out16, int reset);
 /* f1: performOSD_enhanced(H, syndrome, llr, hard, order, max_combinations) (src/decoding/osd.py:5-77), batched.  The OSD-0 solution is
  * returned whenever it reproduces the syndrome (osd.py:27-29); otherwise the <= C(order+10, <= order) flip sets over the least
  * reliable non-pivot positions are scored with recompute_solution / compute_metric (src/decoding/kernels.py:195-219) and the
@@ -175,6 +194,9 @@ int qldpc_cc_plan_read(qldpc_cc_plan *plan, void *stream, int clear, int64_t *ta
 /* time of the decode kernel launches enqueued since the last call, measured with hipEvents on the launch
  * stream (ms, summed) and their count; used by bench.py for the roofline line. */
 int qldpc_cc_plan_kernel_time(qldpc_cc_plan *plan, double *ms_total, int64_t *launches);
+/* shader clock (MHz) held under the last decode launch (plans created with QLDPC_FLAG_CLOCK_PROBE; fused regular kernel only):
+ * median over workgroups of delta(s_memtime) / delta(s_memrealtime) x 100 MHz.  Synchronises `stream`. */
+int qldpc_cc_plan_clock(qldpc_cc_plan *plan, void *stream, double *mhz);
 void qldpc_cc_plan_destroy(qldpc_cc_plan *plan);
 
 /* ---- circuit-level Monte-Carlo (BASELINE config 5) ------------------------------------------------------------
@@ -233,10 +255,45 @@ int qldpc_circuit_plan_run(qldpc_circuit_plan *plan, uint64_t seed, int64_t tria
 int qldpc_circuit_plan_run_outcomes(qldpc_circuit_plan *plan, uint64_t seed, int64_t trial_begin, int64_t count, void *stream,
                                     uint8_t *outcome);
 int qldpc_circuit_plan_read(qldpc_circuit_plan *plan, void *stream, int clear, int64_t *tally);
+/* hipEvent time (ms, summed over the batches enqueued since the last call) of each phase of the per-trial pipeline of
+ * src/simulation/engine.py:68-122, and the number of batches.  Sector X runs on the plan's own stream beside sector Z (unless the plan
+ * was created with QLDPC_FLAG_MC_UNFUSED), so the phase spans overlap and their sum exceeds the wall time. */
+#define QLDPC_CIRCUIT_PHASES 6
+#define QLDPC_PHASE_SAMPLE 0   /* run_trial_fast, engine.py:75 */
+#define QLDPC_PHASE_BP_Z 1     /* engine.py:84-94 */
+#define QLDPC_PHASE_OSD_Z 2    /* engine.py:96-97 */
+#define QLDPC_PHASE_BP_X 3     /* engine.py:103-113 */
+#define QLDPC_PHASE_OSD_X 4    /* engine.py:115-116 */
+#define QLDPC_PHASE_JUDGE 5    /* engine.py:99-100,119-122 + tally */
+int qldpc_circuit_plan_phase_times(qldpc_circuit_plan *plan, double *ms /* [QLDPC_CIRCUIT_PHASES] */, int64_t *batches);
+/* shader clock (MHz) held under the sector-Z decode kernel [0] and OSD-0 kernel [1] of the last batch (plans created with
+ * QLDPC_FLAG_CLOCK_PROBE): median over workgroups of delta(s_memtime) / delta(s_memrealtime) x 100 MHz.  Synchronises `stream`. */
+int qldpc_circuit_plan_clock(qldpc_circuit_plan *plan, void *stream, double *mhz /* [2] */);
 /* the sampler alone = batched run_trial_fast: sparse_z int8[count][#MeasX], true_z int8[count][k], sparse_x, true_x (host) */
 int qldpc_circuit_plan_sample(qldpc_circuit_plan *plan, uint64_t seed, int64_t trial_begin, int64_t count, int8_t *sparse_z,
                               int8_t *true_z, int8_t *sparse_x, int8_t *true_x);
 void qldpc_circuit_plan_destroy(qldpc_circuit_plan *plan);
+
+/* ---- (e) multi-GPU: the one collective of the path, natively on RCCL --------------------------------------------------------
+ * Sum of the int64[QLDPC_TALLY_SLOTS] tally over the GPUs of a node; replaces the Python loop that sums the workers' results in
+ * src/simulation/engine.py:450-457.  librccl is loaded on the first qldpc_comm_* call.  Two ways to form the communicator:
+ *   qldpc_comm_init_all(ndev, devices, &comm)            one process drives `ndev` GPUs (ncclCommInitAll); devices NULL = 0..ndev-1
+ *   qldpc_comm_unique_id(id) on rank 0, id handed to the other ranks by the launcher, then
+ *   qldpc_comm_init_rank(nranks, rank, id, device, &comm)  one process per GPU (ncclCommInitRank)
+ * qldpc_tally_allreduce(comm, tallies): host int64[nlocal][QLDPC_TALLY_SLOTS] (nlocal = ndev after init_all, 1 after init_rank);
+ * on return every row holds the sum over all ranks.  The _dev form reduces a device-resident tally in place on `stream` without
+ * synchronising; with several local ranks, issue the calls of all local ranks between qldpc_comm_group_begin / _end. */
+#define QLDPC_COMM_ID_BYTES 128
+typedef struct qldpc_comm qldpc_comm;
+int qldpc_comm_init_all(int ndev, const int *devices, qldpc_comm **out);
+int qldpc_comm_unique_id(uint8_t *id /* [QLDPC_COMM_ID_BYTES] */);
+int qldpc_comm_init_rank(int nranks, int rank, const uint8_t *id, int device, qldpc_comm **out);
+int qldpc_comm_size(const qldpc_comm *comm, int *nranks, int *nlocal);
+int qldpc_tally_allreduce(qldpc_comm *comm, int64_t *tallies);
+int qldpc_tally_allreduce_dev(qldpc_comm *comm, int local_rank, int64_t *d_tally, void *stream);
+int qldpc_comm_group_begin(void);
+int qldpc_comm_group_end(void);
+void qldpc_comm_destroy(qldpc_comm *comm);
 
 /* Philox4x32-10 reference vector helper (host; lets tests pin the generator against the oracle) */
 void qldpc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

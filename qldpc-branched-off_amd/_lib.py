@@ -8,7 +8,8 @@ from collections import OrderedDict
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libqldpc_hip.so")
+# QLDPC_HIP_SO selects another build of the same ABI at import time (tools/: the diagnostic build with OSD phase timers)
+SO_PATH = os.environ.get("QLDPC_HIP_SO") or os.path.join(_HERE, "csrc", "libqldpc_hip.so")
 
 ALPHA_CONST, ALPHA_DYNAMIC, ALPHA_SEQ = 0, 1, 2
 FLAG_FIXED_ITERS, FLAG_KERNEL_STREAM, FLAG_KERNEL_RESIDENT, FLAG_KERNEL_GENERIC, FLAG_MC_UNFUSED = 0x1, 0x10, 0x20, 0x40, 0x80
@@ -16,20 +17,87 @@ TALLY_SLOTS = 16
 TALLY = {"trials": 0, "z_err": 1, "x_err": 2, "total_err": 3, "bp_conv_z": 4, "bp_conv_x": 5, "osd_z": 6, "osd_x": 7,
          "iters_z": 8, "iters_x": 9, "zero_synd_z": 10, "zero_synd_x": 11, "unsat_z": 12, "unsat_x": 13}
 
-EXPORTS = [
-    "qldpc_last_error", "qldpc_version", "qldpc_device_count", "qldpc_graph_create", "qldpc_graph_destroy", "qldpc_graph_dims",
-    "qldpc_minsum_decode_batch", "qldpc_minsum_decode_batch_dev", "qldpc_minsum_check_pass", "qldpc_bp_check_pass",
-    "qldpc_bp_decode_batch", "qldpc_gf2_spmv_batch", "qldpc_gf2_eliminate", "qldpc_gf2_eliminate_packed", "qldpc_osd0_batch", "qldpc_osd0_batch_dev", "qldpc_osdw_batch", "qldpc_gf2_spmv_batch_dev",
-    "qldpc_noisy_circuit_batch", "qldpc_frame_sim_batch", "qldpc_sparsify_batch", "qldpc_cc_sample_decode_tally",
-    "qldpc_cc_plan_create", "qldpc_cc_plan_run", "qldpc_cc_plan_read", "qldpc_cc_plan_kernel_time", "qldpc_cc_plan_destroy",
-    "qldpc_philox4x32_10", "qldpc_circuit_plan_create", "qldpc_circuit_plan_run", "qldpc_circuit_plan_run_outcomes", "qldpc_circuit_plan_read", "qldpc_circuit_plan_sample",
-    "qldpc_circuit_plan_destroy", "qldpc_circuit_fault_signatures", "qldpc_msgstats_create", "qldpc_msgstats_histogram",
-    "qldpc_msgstats_destroy",
-]
+FLAG_WG_VGLOBAL, FLAG_WG_GENERIC, FLAG_OSD_UG, FLAG_OSD_GLOBAL, FLAG_OSD_NOKILL, FLAG_OSD_LEGACY, FLAG_CLOCK_PROBE, FLAG_WG_ROWMAJOR = (
+    0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000, 0x8000)
+CIRCUIT_PHASES = ("sample", "bp_z", "osd_z", "bp_x", "osd_x", "judge")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "qldpc_hip.h")
 
 
 class QldpcError(RuntimeError):
     pass
+
+
+class CircuitDesc(C.Structure):
+    """qldpc_circuit_desc (include/qldpc_hip.h)."""
+    _fields_ = [("base_len", C.c_int64), ("suffix_len", C.c_int64),
+                ("base_ops", C.POINTER(C.c_int32)), ("base_q1", C.POINTER(C.c_int32)), ("base_q2", C.POINTER(C.c_int32)),
+                ("suffix_ops", C.POINTER(C.c_int32)), ("suffix_q1", C.POINTER(C.c_int32)), ("suffix_q2", C.POINTER(C.c_int32)),
+                ("total_qubits", C.c_int32), ("num_x_checks", C.c_int32), ("num_z_checks", C.c_int32), ("n_data", C.c_int32),
+                ("k", C.c_int32), ("reserved", C.c_int32),
+                ("x_syn_positions", C.POINTER(C.c_int32)), ("x_syn_ptrs", C.POINTER(C.c_int32)),
+                ("z_syn_positions", C.POINTER(C.c_int32)), ("z_syn_ptrs", C.POINTER(C.c_int32)),
+                ("data_qubit_indices", C.POINTER(C.c_int32)), ("Lx", C.POINTER(C.c_uint8)), ("Lz", C.POINTER(C.c_uint8))]
+
+
+_SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "uint32_t": C.c_uint32, "double": C.c_double,
+            "int8_t": C.c_int8, "uint8_t": C.c_uint8, "uint16_t": C.c_uint16}
+
+
+def _ctype_of(decl):
+    """One C parameter declaration of the header -> ctypes type (opaque handles and void* -> c_void_p)."""
+    decl = decl.replace("const", " ").strip()
+    stars = decl.count("*") + decl.count("[")
+    pname = decl.replace("*", " ").split("[")[0].split()[-1]
+    if stars == 1 and pname.startswith("d_"):
+        return C.c_void_p              # device pointer (hipMalloc / torch data_ptr()): passed as an address
+    base = decl.replace("*", " ").split("[")[0].split()
+    base = base[0] if len(base) == 1 else (base[0] if base[0] in _SCALARS or base[0].startswith("qldpc_") or base[0] in ("void", "char") else base[-2])
+    if stars == 0:
+        return _SCALARS[base]
+    if base == "qldpc_circuit_desc":
+        t = CircuitDesc
+    elif base in ("void", "char") or base.startswith("qldpc_"):
+        t = None                       # opaque: void*
+    else:
+        t = _SCALARS[base]
+    if t is None:
+        return C.c_void_p if stars == 1 else C.POINTER(C.c_void_p)
+    for _ in range(stars):
+        t = C.POINTER(t)
+    return t
+
+
+def parse_header(path=HEADER_PATH):
+    """{name: (restype, [argtypes])} for every function include/qldpc_hip.h declares: the binding is derived from the C ABI itself,
+    so a mistyped or missing argument raises ctypes.ArgumentError instead of corrupting memory."""
+    import re
+    with open(path) as fh:
+        text = fh.read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    out = {}
+    for ret, name, args in re.findall(r"\b(const\s+char\s*\*|int|void)\s*(qldpc_\w+)\s*\(([^;{}]*?)\)\s*;", text):
+        ret = ret.replace(" ", "")
+        restype = C.c_char_p if ret.startswith("constchar") else (C.c_int if ret == "int" else None)
+        args = args.strip()
+        argtypes = [] if args in ("", "void") else [_ctype_of(a) for a in args.split(",")]
+        out[name] = (restype, argtypes)
+    return out
+
+
+_SIGNATURES = None
+
+
+def signatures():
+    global _SIGNATURES
+    if _SIGNATURES is None:
+        _SIGNATURES = parse_header()
+    return _SIGNATURES
+
+
+def exports():
+    """Names of every function the C ABI declares."""
+    return sorted(signatures())
 
 
 _lib = None
@@ -46,16 +114,10 @@ def lib():
                     raise QldpcError(f"HIP extension missing: {SO_PATH} (build it with `make -C {os.path.dirname(SO_PATH)}` "
                                      "or __graft_entry__.build()); there is no CPU fallback")
                 L = C.CDLL(SO_PATH)
-                L.qldpc_last_error.restype = C.c_char_p
-                for name in EXPORTS:
-                    if name not in ("qldpc_last_error", "qldpc_graph_destroy", "qldpc_cc_plan_destroy", "qldpc_philox4x32_10",
-                                    "qldpc_circuit_plan_destroy", "qldpc_msgstats_destroy"):
-                        getattr(L, name).restype = C.c_int
-                L.qldpc_graph_destroy.restype = None
-                L.qldpc_cc_plan_destroy.restype = None
-                L.qldpc_philox4x32_10.restype = None
-                L.qldpc_circuit_plan_destroy.restype = None
-                L.qldpc_msgstats_destroy.restype = None
+                for name, (restype, argtypes) in signatures().items():
+                    fn = getattr(L, name)          # AttributeError here = the library lacks a declared symbol
+                    fn.restype = restype
+                    fn.argtypes = argtypes
                 _lib = L
     return _lib
 
@@ -201,6 +263,100 @@ def minsum_decode_batch(graph, syndromes, prior, max_iter, alpha_mode, alpha, da
     return err, conv, llr, iters
 
 
+def osd0_batch(graph, syndromes, llr, hard, ordering=None, flags=0):
+    """qldpc_osd0_batch on host arrays: OSD-0 solutions int8[B, n] (performOSD_enhanced with order = 0, osd.py:5-29)."""
+    syndromes = i8(syndromes).reshape(-1, graph.m) if graph.m else np.zeros((np.asarray(hard).reshape(-1, graph.n).shape[0], 0), np.int8)
+    B = syndromes.shape[0]
+    llr, hard = f64(llr).reshape(B, graph.n), i8(hard).reshape(B, graph.n)
+    sol = np.zeros((B, graph.n), np.int8)
+    op = None
+    if ordering is not None:
+        ordering = i32(ordering).reshape(B, graph.n)
+        op = ptr(ordering, C.c_int32)
+    check(lib().qldpc_osd0_batch(graph.handle, B, ptr(syndromes, C.c_int8), ptr(llr, C.c_double), ptr(hard, C.c_int8), op, int(flags), ptr(sol, C.c_int8)))
+    return sol
+
+
+def osdw_batch(graph, syndromes, llr, hard, order, max_combinations=None, ordering=None):
+    """qldpc_osdw_batch on host arrays: performOSD_enhanced(order, max_combinations) (osd.py:5-77) for B shots -> int8[B, n]."""
+    syndromes = i8(syndromes).reshape(-1, graph.m)
+    B = syndromes.shape[0]
+    llr, hard = f64(llr).reshape(B, graph.n), i8(hard).reshape(B, graph.n)
+    sol = np.zeros((B, graph.n), np.int8)
+    op = None
+    if ordering is not None:
+        ordering = i32(ordering).reshape(B, graph.n)
+        op = ptr(ordering, C.c_int32)
+    check(lib().qldpc_osdw_batch(graph.handle, B, ptr(syndromes, C.c_int8), ptr(llr, C.c_double), ptr(hard, C.c_int8), op, int(order),
+                                 int(max_combinations or 0), ptr(sol, C.c_int8)))
+    return sol
+
+
+def gf2_spmv_batch(graph, vectors):
+    """s = H e over GF(2) for B vectors (qldpc_gf2_spmv_batch, kernels.py:222-231): int8[B, n] -> int8[B, m]."""
+    vectors = i8(vectors).reshape(-1, graph.n)
+    out = np.zeros((vectors.shape[0], graph.m), np.int8)
+    check(lib().qldpc_gf2_spmv_batch(graph.handle, vectors.shape[0], ptr(vectors, C.c_int8), ptr(out, C.c_int8)))
+    return out
+
+
+def osd_timers(reset=True):
+    """Phase counters of the OSD-0 kernels (diagnostic build only, see csrc/osd_common.h) -> uint64[16]."""
+    out = np.zeros(16, np.uint64)
+    check(lib().qldpc_osd_timers_read(ptr(out, C.c_uint64), int(reset)))
+    return out
+
+
+class Comm:
+    """RCCL communicator of the tally all-reduce (qldpc_comm_*): `Comm.init_all(ndev)` for one process driving ndev GPUs,
+    `Comm.init_rank(nranks, rank, id, device)` for one process per GPU (id = Comm.unique_id() of rank 0, handed over by the launcher)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        nr, nl = C.c_int(0), C.c_int(0)
+        check(lib().qldpc_comm_size(self._h, C.byref(nr), C.byref(nl)))
+        self.nranks, self.nlocal = nr.value, nl.value
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(128, np.uint8)
+        check(lib().qldpc_comm_unique_id(ptr(buf, C.c_uint8)))
+        return buf.tobytes()
+
+    @classmethod
+    def init_all(cls, ndev, devices=None):
+        require_device()
+        h = C.c_void_p()
+        dv = None if devices is None else ptr(np.ascontiguousarray(devices, np.int32), C.c_int)
+        check(lib().qldpc_comm_init_all(int(ndev), dv, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def init_rank(cls, nranks, rank, uid, device):
+        require_device()
+        h = C.c_void_p()
+        buf = np.frombuffer(bytes(uid), np.uint8).copy()
+        check(lib().qldpc_comm_init_rank(int(nranks), int(rank), ptr(buf, C.c_uint8), int(device), C.byref(h)))
+        return cls(h)
+
+    def allreduce(self, tallies):
+        """int64[nlocal, 16] (or [16] when nlocal == 1) -> the sum over all ranks, same shape."""
+        t = np.ascontiguousarray(tallies, np.int64).reshape(self.nlocal, TALLY_SLOTS).copy()
+        check(lib().qldpc_tally_allreduce(self._h, ptr(t, C.c_int64)))
+        return t.reshape(np.shape(tallies))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().qldpc_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def cc_sample_decode_tally(graph, L, p, seed, shot_begin, count, max_iter=50, alpha=1.0, alpha_mode="dynamical", damping=1.0,
                            clip_llr=20.0, use_osd=True, flags=0):
     mode, aval, seq = alpha_args(alpha_mode, alpha)
@@ -239,6 +395,12 @@ class CodeCapacityPlan:
         check(lib().qldpc_cc_plan_kernel_time(self._h, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
 
+    def clock(self, stream=0):
+        """Shader clock (MHz) held under the last fused decode launch (plan created with FLAG_CLOCK_PROBE)."""
+        mhz = C.c_double(0)
+        check(lib().qldpc_cc_plan_clock(self._h, C.c_void_p(stream), C.byref(mhz)))
+        return float(mhz.value)
+
     def close(self):
         if self._h is not None and self._h.value:
             lib().qldpc_cc_plan_destroy(self._h)
@@ -249,18 +411,6 @@ class CodeCapacityPlan:
             self.close()
         except Exception:
             pass
-
-
-class CircuitDesc(C.Structure):
-    """qldpc_circuit_desc (include/qldpc_hip.h)."""
-    _fields_ = [("base_len", C.c_int64), ("suffix_len", C.c_int64),
-                ("base_ops", C.POINTER(C.c_int32)), ("base_q1", C.POINTER(C.c_int32)), ("base_q2", C.POINTER(C.c_int32)),
-                ("suffix_ops", C.POINTER(C.c_int32)), ("suffix_q1", C.POINTER(C.c_int32)), ("suffix_q2", C.POINTER(C.c_int32)),
-                ("total_qubits", C.c_int32), ("num_x_checks", C.c_int32), ("num_z_checks", C.c_int32), ("n_data", C.c_int32),
-                ("k", C.c_int32), ("reserved", C.c_int32),
-                ("x_syn_positions", C.POINTER(C.c_int32)), ("x_syn_ptrs", C.POINTER(C.c_int32)),
-                ("z_syn_positions", C.POINTER(C.c_int32)), ("z_syn_ptrs", C.POINTER(C.c_int32)),
-                ("data_qubit_indices", C.POINTER(C.c_int32)), ("Lx", C.POINTER(C.c_uint8)), ("Lz", C.POINTER(C.c_uint8))]
 
 
 def _attr(src, name):
@@ -363,22 +513,12 @@ class CircuitPlan:
                  alpha_mode="dynamical", damping=1.0, clip_llr=20.0, use_osd=True, flags=0, batch=16384):
         mode, az, sz = alpha_args(alpha_mode, alpha_z)
         _, ax, sx = alpha_args(alpha_mode, alpha_x)
-        keep = {k: i32(_attr(compiled, k)) for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions",
-                                                     "x_syn_ptrs", "z_syn_positions", "z_syn_ptrs", "data_qubit_indices")}
-        keep["Lx"], keep["Lz"] = u8(Lx), u8(Lz)
-        d = CircuitDesc()
-        d.base_len, d.suffix_len = keep["base_ops"].size, keep["suffix_ops"].size
-        for k in ("base_ops", "base_q1", "base_q2", "suffix_ops", "suffix_q1", "suffix_q2", "x_syn_positions", "x_syn_ptrs", "z_syn_positions",
-                  "z_syn_ptrs", "data_qubit_indices"):
-            setattr(d, k, ptr(keep[k], C.c_int32))
-        d.total_qubits = int(_attr(compiled, "total_qubits"))
-        d.num_x_checks, d.num_z_checks = keep["x_syn_ptrs"].size - 1, keep["z_syn_ptrs"].size - 1
-        d.n_data, d.k = keep["data_qubit_indices"].size, keep["Lx"].shape[0]
-        d.Lx, d.Lz = ptr(keep["Lx"], C.c_uint8), ptr(keep["Lz"], C.c_uint8)
+        d, keep = make_circuit_desc(compiled, Lx, Lz)
         pz, px = f64(prior_z), f64(prior_x)
         lz, lx = np.ascontiguousarray(logmask_z, np.uint64), np.ascontiguousarray(logmask_x, np.uint64)
         self.k, self.nsx, self.nsz = d.k, int(keep["x_syn_ptrs"][-1]), int(keep["z_syn_ptrs"][-1])
         self.graph_z, self.graph_x = graph_z, graph_x
+        self.flags = flags
         self._h = C.c_void_p()
         check(lib().qldpc_circuit_plan_create(C.byref(d), graph_z.handle, graph_x.handle, ptr(pz, C.c_double), ptr(px, C.c_double),
                                               ptr(lz, C.c_uint64), ptr(lx, C.c_uint64), C.c_double(p), C.c_int(max_iter), C.c_int(mode),
@@ -400,6 +540,19 @@ class CircuitPlan:
         tally = np.zeros(TALLY_SLOTS, np.int64)
         check(lib().qldpc_circuit_plan_read(self._h, C.c_void_p(stream), C.c_int(int(clear)), ptr(tally, C.c_int64)))
         return tally
+
+    def phase_times(self):
+        """({phase: ms summed over the batches since the last call}, batches): hipEvent brackets of sampler / BP / OSD-0 per sector / judge."""
+        ms = (C.c_double * len(CIRCUIT_PHASES))()
+        nb = C.c_int64(0)
+        check(lib().qldpc_circuit_plan_phase_times(self._h, ms, C.byref(nb)))
+        return {k: float(ms[i]) for i, k in enumerate(CIRCUIT_PHASES)}, int(nb.value)
+
+    def clock(self, stream=0):
+        """Shader clock (MHz) under the sector-Z decode and OSD-0 kernels of the last batch (plan created with FLAG_CLOCK_PROBE)."""
+        mhz = (C.c_double * 2)()
+        check(lib().qldpc_circuit_plan_clock(self._h, C.c_void_p(stream), mhz))
+        return float(mhz[0]), float(mhz[1])
 
     def sample(self, seed, trial_begin, count):
         """Batched run_trial_fast -> (sparse_z int8[count, nsx], true_z int8[count, k], sparse_x, true_x)."""

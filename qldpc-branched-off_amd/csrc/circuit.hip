@@ -193,13 +193,42 @@ struct qldpc_circuit_plan {
     DevBuf d_loc_type, d_zptr, d_zidx, d_zlog, d_xptr, d_xidx, d_xlog;
     DevBuf d_alpha_z, d_alpha_x, d_prior_z, d_prior_x, d_lm_z, d_lm_x;
     DevBuf d_syn_z, d_syn_x, d_true_z, d_true_x, d_det_z, d_det_x, d_llr_z, d_llr_x, d_conv_z, d_conv_x, d_iter_z, d_iter_x;
-    DevBuf d_list, d_count, d_tally, d_outcome;
+    DevBuf d_list_z, d_list_x, d_count, d_tally, d_outcome, d_clk;    // d_count: [0] Z failures, [4] X failures (int32, 16 bytes apart)
+    // The two sectors are independent between the sampler and the judge: sector X runs on the plan's own stream so its decode fills the CUs the
+    // tail of sector Z's OSD launch leaves idle (and vice versa); QLDPC_FLAG_MC_UNFUSED keeps everything on the caller's stream.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_sampled = nullptr, ev_x_done = nullptr;
+    // hipEvent brackets of the phases of every batch not yet read by qldpc_circuit_plan_phase_times
+    struct Bracket { int phase; hipEvent_t a, b; };
+    std::vector<Bracket> pending;
+    std::vector<hipEvent_t> pool;
+    double phase_ms[QLDPC_CIRCUIT_PHASES] = {0, 0, 0, 0, 0, 0};
+    int64_t batches = 0;
     std::vector<DevBuf *> all() {
         return {&d_loc_type, &d_zptr, &d_zidx, &d_zlog, &d_xptr, &d_xidx, &d_xlog, &d_alpha_z, &d_alpha_x, &d_prior_z, &d_prior_x, &d_lm_z, &d_lm_x,
                 &d_syn_z, &d_syn_x, &d_true_z, &d_true_x, &d_det_z, &d_det_x, &d_llr_z, &d_llr_x, &d_conv_z, &d_conv_x, &d_iter_z, &d_iter_x,
-                &d_list, &d_count, &d_tally, &d_outcome};
+                &d_list_z, &d_list_x, &d_count, &d_tally, &d_outcome, &d_clk};
     }
 };
+
+static hipEvent_t plan_event(qldpc_circuit_plan *P) {
+    if (!P->pool.empty()) { hipEvent_t e = P->pool.back(); P->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+// brackets `phase` on stream s: call once before (open = true) and once after the launches
+static int phase_mark(qldpc_circuit_plan *P, int phase, hipStream_t s, bool open) {
+    hipEvent_t e = plan_event(P);
+    if (!e) { set_error("hipEventCreate failed"); return QLDPC_ERR_HIP; }
+    QLDPC_HIP_TRY(hipEventRecord(e, s));
+    if (open) P->pending.push_back({phase, e, nullptr});
+    else {
+        for (auto it = P->pending.rbegin(); it != P->pending.rend(); ++it)
+            if (it->phase == phase && it->b == nullptr) { it->b = e; return QLDPC_OK; }
+        P->pool.push_back(e);
+    }
+    return QLDPC_OK;
+}
 
 template <class T>
 static int up(DevBuf &b, const std::vector<T> &v) {
@@ -307,7 +336,7 @@ QLDPC_EXPORT int qldpc_circuit_fault_signatures(const qldpc_circuit_desc *D, int
     int rc = validate_desc(D);
     if (rc != QLDPC_OK) return rc;
     QLDPC_REQUIRE(ptr && logmask && idx_needed && (idx || idx_cap == 0), "NULL output");
-    if ((rc = use_device(0)) != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(0);
     std::vector<int32_t> ops(D->base_ops, D->base_ops + D->base_len), q1(D->base_q1, D->base_q1 + D->base_len), q2(D->base_q2, D->base_q2 + D->base_len);
     ops.insert(ops.end(), D->suffix_ops, D->suffix_ops + D->suffix_len);
     q1.insert(q1.end(), D->suffix_q1, D->suffix_q1 + D->suffix_len);
@@ -342,7 +371,7 @@ QLDPC_EXPORT int qldpc_circuit_plan_create(const qldpc_circuit_desc *D, const ql
     const int nsx = D->x_syn_ptrs[D->num_x_checks], nsz = D->z_syn_ptrs[D->num_z_checks];
     QLDPC_REQUIRE(gz->m == nsx && gx->m == nsz, "decoding matrices have %d / %d rows but the circuit measures %d X / %d Z syndromes", gz->m, gx->m, nsx, nsz);
     QLDPC_REQUIRE(nsx < 65536 && nsz < 65536, "too many detectors for 16-bit signature indices");
-    if ((rc = use_device(gz->device)) != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(gz->device);
 
     std::vector<int32_t> ops(D->base_ops, D->base_ops + D->base_len), q1(D->base_q1, D->base_q1 + D->base_len), q2(D->base_q2, D->base_q2 + D->base_len);
     ops.insert(ops.end(), D->suffix_ops, D->suffix_ops + D->suffix_len);
@@ -378,8 +407,17 @@ QLDPC_EXPORT int qldpc_circuit_plan_create(const qldpc_circuit_desc *D, const ql
     if ((rc = P->d_syn_z.ensure(Bz * nsx)) || (rc = P->d_syn_x.ensure(Bz * nsz)) || (rc = P->d_true_z.ensure(Bz * 8)) || (rc = P->d_true_x.ensure(Bz * 8)) ||
         (rc = P->d_det_z.ensure(Bz * gz->n)) || (rc = P->d_det_x.ensure(Bz * gx->n)) || (rc = P->d_llr_z.ensure(Bz * gz->n * 8)) ||
         (rc = P->d_llr_x.ensure(Bz * gx->n * 8)) || (rc = P->d_conv_z.ensure(Bz)) || (rc = P->d_conv_x.ensure(Bz)) || (rc = P->d_iter_z.ensure(Bz * 4)) ||
-        (rc = P->d_iter_x.ensure(Bz * 4)) || (rc = P->d_list.ensure(Bz * 4)) || (rc = P->d_count.ensure(16)) || (rc = P->d_tally.ensure(QLDPC_TALLY_SLOTS * 8)))
+        (rc = P->d_iter_x.ensure(Bz * 4)) || (rc = P->d_list_z.ensure(Bz * 4)) || (rc = P->d_list_x.ensure(Bz * 4)) || (rc = P->d_count.ensure(64)) ||
+        (rc = P->d_tally.ensure(QLDPC_TALLY_SLOTS * 8)) || (rc = P->d_clk.ensure(2 * kClkSlots * 16)))
         return fail(rc);
+    if (hipMemset(P->d_clk.p, 0, 2 * kClkSlots * 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
+    if (!(flags & QLDPC_FLAG_MC_UNFUSED)) {
+        if (hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&P->ev_sampled, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&P->ev_x_done, hipEventDisableTiming) != hipSuccess) {
+            set_error("stream / event creation failed: %s", hipGetErrorString(hipGetLastError()));
+            return fail(QLDPC_ERR_HIP);
+        }
+    }
     if (hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
     *out = P;
     return QLDPC_OK;
@@ -399,39 +437,61 @@ static int launch_sampler(qldpc_circuit_plan *P, uint64_t seed, int64_t begin, i
 }
 
 static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B, DevBuf &syn, DevBuf &prior, DevBuf &alpha, DevBuf &det, DevBuf &llr,
-                         DevBuf &conv, DevBuf &iter, int osd_slot, hipStream_t s) {
+                         DevBuf &conv, DevBuf &iter, DevBuf &list, int sector, hipStream_t s) {
     int rc;
+    int32_t *count = P->d_count.as<int32_t>() + 4 * sector;
+    const int ph_bp = sector ? QLDPC_PHASE_BP_X : QLDPC_PHASE_BP_Z, ph_osd = sector ? QLDPC_PHASE_OSD_X : QLDPC_PHASE_OSD_Z;
+    unsigned long long *clk = (P->flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() : nullptr;
+    if ((rc = phase_mark(P, ph_bp, s, true)) != QLDPC_OK) return rc;
     {
         std::lock_guard<std::mutex> lk(g->mu);
+        g->clk_probe = (clk && sector == 0) ? clk : nullptr;                  // sector Z carries the probe (one writer per buffer)
         rc = minsum_decode_dispatch(g, B, syn.as<int8_t>(), prior.as<double>(), P->max_iter, alpha.as<double>(), P->damping, P->clip,
                                     (P->flags & 0xFFFF) | (P->nanfree ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0),
                                     P->nanfree, det.as<int8_t>(), llr.as<double>(), conv.as<uint8_t>(), iter.as<int32_t>(), s);
-    }
-    if (rc != QLDPC_OK || !P->use_osd) return rc;
-    QLDPC_HIP_TRY(hipMemsetAsync(P->d_count.p, 0, 4, s));
-    hipLaunchKernelGGL(collect_failed2_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, conv.as<uint8_t>(), P->d_list.as<int32_t>(),
-                       P->d_count.as<int32_t>());
-    {
-        std::lock_guard<std::mutex> lk(g->mu);
-        rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), syn.as<int8_t>(), llr.as<double>(), det.as<int8_t>(), nullptr,
-                                det.as<int8_t>(), s);
+        g->clk_probe = nullptr;
     }
     if (rc != QLDPC_OK) return rc;
-    hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(64), 0, s, P->d_count.as<int32_t>(), P->d_tally.as<unsigned long long>() + osd_slot);
+    if ((rc = phase_mark(P, ph_bp, s, false)) != QLDPC_OK || !P->use_osd) return rc;
+    if ((rc = phase_mark(P, ph_osd, s, true)) != QLDPC_OK) return rc;
+    QLDPC_HIP_TRY(hipMemsetAsync(count, 0, 4, s));
+    hipLaunchKernelGGL(collect_failed2_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, conv.as<uint8_t>(), list.as<int32_t>(), count);
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->clk_probe = (clk && sector == 0) ? clk + 2 * kClkSlots : nullptr;
+        rc = osd0_listed_launch(g, list.as<int32_t>(), count, syn.as<int8_t>(), llr.as<double>(), det.as<int8_t>(), nullptr,
+                                det.as<int8_t>(), P->flags, s);
+        g->clk_probe = nullptr;
+    }
+    if (rc != QLDPC_OK) return rc;
+    hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(64), 0, s, count, P->d_tally.as<unsigned long long>() + (sector ? QLDPC_TALLY_OSD_X : QLDPC_TALLY_OSD_Z));
     QLDPC_HIP_TRY(hipGetLastError());
-    return QLDPC_OK;
+    return phase_mark(P, ph_osd, s, false);
 }
 
 // one pass over [trial_begin, trial_begin + count); `outcome` (host, may be NULL) receives bit0 = z_err, bit1 = x_err per trial
 static int circuit_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin, int64_t count, hipStream_t s, uint8_t *outcome) {
-    int rc = use_device(P->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(P->device);
+    int rc = QLDPC_OK; (void)rc;
     if (outcome && (rc = P->d_outcome.ensure((size_t)P->batch)) != QLDPC_OK) return rc;
     for (int64_t off = 0; off < count; off += P->batch) {
         const int64_t B = std::min<int64_t>(P->batch, count - off);
+        if ((rc = phase_mark(P, QLDPC_PHASE_SAMPLE, s, true)) != QLDPC_OK) return rc;
         if ((rc = launch_sampler(P, seed, trial_begin + off, B, s)) != QLDPC_OK) return rc;
-        if ((rc = decode_sector(P, P->gz, B, P->d_syn_z, P->d_prior_z, P->d_alpha_z, P->d_det_z, P->d_llr_z, P->d_conv_z, P->d_iter_z, QLDPC_TALLY_OSD_Z, s)) != QLDPC_OK) return rc;
-        if ((rc = decode_sector(P, P->gx, B, P->d_syn_x, P->d_prior_x, P->d_alpha_x, P->d_det_x, P->d_llr_x, P->d_conv_x, P->d_iter_x, QLDPC_TALLY_OSD_X, s)) != QLDPC_OK) return rc;
+        if ((rc = phase_mark(P, QLDPC_PHASE_SAMPLE, s, false)) != QLDPC_OK) return rc;
+        hipStream_t sx = s;
+        if (P->side && P->gz != P->gx) {                // sector X on the plan's own stream, joined again before the judge
+            sx = P->side;
+            QLDPC_HIP_TRY(hipEventRecord(P->ev_sampled, s));
+            QLDPC_HIP_TRY(hipStreamWaitEvent(sx, P->ev_sampled, 0));
+        }
+        if ((rc = decode_sector(P, P->gz, B, P->d_syn_z, P->d_prior_z, P->d_alpha_z, P->d_det_z, P->d_llr_z, P->d_conv_z, P->d_iter_z, P->d_list_z, 0, s)) != QLDPC_OK) return rc;
+        if ((rc = decode_sector(P, P->gx, B, P->d_syn_x, P->d_prior_x, P->d_alpha_x, P->d_det_x, P->d_llr_x, P->d_conv_x, P->d_iter_x, P->d_list_x, 1, sx)) != QLDPC_OK) return rc;
+        if (sx != s) {
+            QLDPC_HIP_TRY(hipEventRecord(P->ev_x_done, sx));
+            QLDPC_HIP_TRY(hipStreamWaitEvent(s, P->ev_x_done, 0));
+        }
+        if ((rc = phase_mark(P, QLDPC_PHASE_JUDGE, s, true)) != QLDPC_OK) return rc;
         JudgeSector Z{P->gz->m, P->gz->n, P->gz->d_indptr, P->gz->d_indices, P->d_lm_z.as<uint64_t>(), P->d_syn_z.as<int8_t>(), P->d_det_z.as<int8_t>(),
                       P->d_conv_z.as<uint8_t>(), P->d_iter_z.as<int32_t>(), P->d_true_z.as<unsigned long long>()};
         JudgeSector X{P->gx->m, P->gx->n, P->gx->d_indptr, P->gx->d_indices, P->d_lm_x.as<uint64_t>(), P->d_syn_x.as<int8_t>(), P->d_det_x.as<int8_t>(),
@@ -439,6 +499,8 @@ static int circuit_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin
         hipLaunchKernelGGL(circuit_judge_kernel, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, B, Z, X, P->d_tally.as<unsigned long long>(),
                            outcome ? P->d_outcome.as<uint8_t>() : (uint8_t *)nullptr);
         QLDPC_HIP_TRY(hipGetLastError());
+        if ((rc = phase_mark(P, QLDPC_PHASE_JUDGE, s, false)) != QLDPC_OK) return rc;
+        P->batches++;           // (the next batch's sampler follows the judge on s, which already waited for sector X)
         if (outcome) {
             QLDPC_HIP_TRY(hipMemcpyAsync(outcome + off, P->d_outcome.p, (size_t)B, hipMemcpyDeviceToHost, s));
             QLDPC_HIP_TRY(hipStreamSynchronize(s));
@@ -463,8 +525,8 @@ QLDPC_EXPORT int qldpc_circuit_plan_run_outcomes(qldpc_circuit_plan *P, uint64_t
 
 QLDPC_EXPORT int qldpc_circuit_plan_read(qldpc_circuit_plan *P, void *stream, int clear, int64_t *tally) {
     QLDPC_REQUIRE(P != nullptr && tally != nullptr, "NULL argument");
-    int rc = use_device(P->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(P->device);
+    int rc = QLDPC_OK; (void)rc;
     QLDPC_HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
     QLDPC_HIP_TRY(hipMemcpy(tally, P->d_tally.p, QLDPC_TALLY_SLOTS * 8, hipMemcpyDeviceToHost));
     if (clear) QLDPC_HIP_TRY(hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8));
@@ -477,8 +539,8 @@ QLDPC_EXPORT int qldpc_circuit_plan_sample(qldpc_circuit_plan *P, uint64_t seed,
     QLDPC_REQUIRE(P != nullptr, "plan is NULL");
     QLDPC_REQUIRE(count >= 0 && trial_begin >= 0, "negative trial range");
     QLDPC_REQUIRE(count == 0 || (sparse_z && true_z && sparse_x && true_x), "NULL output");
-    int rc = use_device(P->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(P->device);
+    int rc = QLDPC_OK; (void)rc;
     std::vector<unsigned long long> tz, tx;
     for (int64_t off = 0; off < count; off += P->batch) {
         const int64_t B = std::min<int64_t>(P->batch, count - off);
@@ -498,9 +560,50 @@ QLDPC_EXPORT int qldpc_circuit_plan_sample(qldpc_circuit_plan *P, uint64_t seed,
     return QLDPC_OK;
 }
 
+// Sums (ms) of the hipEvent brackets of each phase over the batches enqueued since the last call, and the number of batches.  With the
+// two sectors on two streams the brackets overlap in time: their sum exceeds the wall time, each is the span of that phase on its stream.
+QLDPC_EXPORT int qldpc_circuit_plan_phase_times(qldpc_circuit_plan *P, double *ms, int64_t *batches) {
+    QLDPC_REQUIRE(P != nullptr && ms != nullptr, "NULL argument");
+    QLDPC_USE_DEVICE(P->device);
+    for (auto &br : P->pending) {
+        if (br.b) {
+            QLDPC_HIP_TRY(hipEventSynchronize(br.b));
+            float t = 0;
+            QLDPC_HIP_TRY(hipEventElapsedTime(&t, br.a, br.b));
+            P->phase_ms[br.phase] += t;
+            P->pool.push_back(br.b);
+        }
+        P->pool.push_back(br.a);
+    }
+    P->pending.clear();
+    for (int i = 0; i < QLDPC_CIRCUIT_PHASES; i++) { ms[i] = P->phase_ms[i]; P->phase_ms[i] = 0; }
+    if (batches) *batches = P->batches;
+    P->batches = 0;
+    return QLDPC_OK;
+}
+
+// Shader clock (MHz) held while the decode kernel [0] and the OSD-0 kernel [1] of sector Z ran in the last batch: median over workgroups of
+// delta(s_memtime) / delta(s_memrealtime) x 100 MHz.  Needs QLDPC_FLAG_CLOCK_PROBE at plan creation; 0 where nothing was stamped.
+QLDPC_EXPORT int qldpc_circuit_plan_clock(qldpc_circuit_plan *P, void *stream, double *mhz) {
+    QLDPC_REQUIRE(P != nullptr && mhz != nullptr, "NULL argument");
+    QLDPC_REQUIRE(P->flags & QLDPC_FLAG_CLOCK_PROBE, "the plan was created without QLDPC_FLAG_CLOCK_PROBE");
+    QLDPC_USE_DEVICE(P->device);
+    QLDPC_HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    if (P->side) QLDPC_HIP_TRY(hipStreamSynchronize(P->side));
+    std::vector<unsigned long long> h(4 * kClkSlots);
+    QLDPC_HIP_TRY(hipMemcpy(h.data(), P->d_clk.p, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 2; k++) mhz[k] = clock_probe_median(h.data() + 2 * kClkSlots * k, kClkSlots);
+    return QLDPC_OK;
+}
+
 QLDPC_EXPORT void qldpc_circuit_plan_destroy(qldpc_circuit_plan *P) {
     if (!P) return;
     (void)hipSetDevice(P->device);
+    if (P->side) { (void)hipStreamSynchronize(P->side); (void)hipStreamDestroy(P->side); }
+    if (P->ev_sampled) (void)hipEventDestroy(P->ev_sampled);
+    if (P->ev_x_done) (void)hipEventDestroy(P->ev_x_done);
+    for (auto &br : P->pending) { (void)hipEventDestroy(br.a); if (br.b) (void)hipEventDestroy(br.b); }
+    for (auto e : P->pool) (void)hipEventDestroy(e);
     for (DevBuf *b : P->all()) b->release();
     delete P;
 }

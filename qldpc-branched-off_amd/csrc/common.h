@@ -37,6 +37,23 @@ void set_error(const char *fmt, ...);
 // Checks that a gfx9 device is present and selects it. Returns QLDPC_OK or QLDPC_ERR_NO_DEVICE.
 int use_device(int device);
 
+// Entry points select their handle's device for the calling thread and put the caller's current device back on return
+// (a process that also drives the GPU through another runtime, e.g. torch, keeps its own current device).
+struct DeviceScope {
+    int prev = -1;
+    int enter(int device);
+    ~DeviceScope();
+};
+#define QLDPC_USE_DEVICE(dev)                                   \
+    qldpc::DeviceScope _dev_scope;                              \
+    {                                                           \
+        const int _rc_dev = _dev_scope.enter(dev);              \
+        if (_rc_dev != QLDPC_OK) return _rc_dev;                \
+    }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set it once per (device, kernel), thread-safe.
+int ensure_max_lds(int device, const void *func, int bytes);
+
 // Grow-only device buffer (never shrinks; freed with the owner).
 struct DevBuf {
     void *p = nullptr;
@@ -61,6 +78,24 @@ struct DevTmp {
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
+// Shader-clock probe (QLDPC_FLAG_CLOCK_PROBE): thread 0 of a workgroup stamps the shader-clock counter (s_memtime) and the constant
+// 100 MHz counter (s_memrealtime) when it starts and when it ends; clock held under this kernel's load = delta ratio x 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back item 6).  Buffer: kClkSlots pairs (delta memtime, delta memrealtime) indexed by blockIdx.x.
+constexpr int kClkSlots = 512;
+struct ClkStamp { unsigned long long t = 0, r = 0; };
+__device__ __forceinline__ ClkStamp clk_begin(const unsigned long long *clk) {
+    ClkStamp s;
+    if (clk) { s.t = __builtin_amdgcn_s_memtime(); s.r = __builtin_amdgcn_s_memrealtime(); }
+    return s;
+}
+__device__ __forceinline__ void clk_end(unsigned long long *clk, const ClkStamp &s) {
+    if (clk && threadIdx.x == 0 && blockIdx.x < kClkSlots) {
+        clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - s.t;
+        clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - s.r;
+    }
+}
+double clock_probe_median(const unsigned long long *pairs, int slots);   // MHz; 0 when nothing was stamped
+
 }  // namespace qldpc
 
 // Tanner graph handle.  Host CSR/CSC plus device copies; immutable after create except the workspace cache.
@@ -76,13 +111,25 @@ struct qldpc_graph {
     // ELL (slot-major) views for the workgroup-per-shot kernel: coalesced index loads across rows / columns
     uint16_t *d_ell_col = nullptr;   // [round_up(max_row_deg, 8)][m]  column of the k-th edge of row i; unused slots hold column 0
     uint32_t *d_ell_var = nullptr;   // [max_col_deg][n]  (row << 8) | position-in-row of the d-th edge of column j (ascending rows)
-    // workspace cache for the decode kernels (guarded by mu; one decode at a time per graph handle)
+    // Device workspaces of the decode / OSD kernels.  `mu` guards the bookkeeping while launches are enqueued; the buffers themselves
+    // are protected in STREAM order: every user calls ws_acquire(stream) before its launches and ws_release(stream) after them, so a
+    // launch on another stream first waits (hipStreamWaitEvent) for the previous user of the workspaces to finish.
     mutable std::mutex mu;
-    mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_alpha, ws_misc, ws_queue, ws_list;
+    mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_misc, ws_queue, ws_list;
+    mutable hipEvent_t ws_event = nullptr;
+    mutable hipStream_t ws_stream = nullptr;
+    mutable bool ws_used = false;
+    int ws_acquire(hipStream_t stream) const;     // callers hold mu
+    int ws_release(hipStream_t stream) const;
     mutable std::mutex mu_io;        // host-pointer entry points: serialises use of ws_io (taken before mu)
     mutable qldpc::DevBuf ws_io;
-    mutable std::vector<double> alpha_host;   // alpha table currently in ws_alpha (guarded by mu)
+    // alpha tables already on the device (guarded by mu).  A table is uploaded once from a pinned host copy and never overwritten, so
+    // the *_dev entry points stay pure enqueues (no synchronisation) however the alpha schedule changes between calls.
+    struct AlphaEntry { std::vector<double> host; double *pinned = nullptr; double *dev = nullptr; hipEvent_t ready = nullptr; hipStream_t stream = nullptr; };
+    mutable std::vector<AlphaEntry> alpha_cache;
+    int alpha_table(const std::vector<double> &tab, hipStream_t stream, const double **d_out) const;   // callers hold mu
     mutable void *pin = nullptr;     // pinned host staging for small results
     mutable size_t pin_cap = 0;
     mutable int gf2_rank = -1;       // rank of H over GF(2), computed on first OSD use
+    mutable unsigned long long *clk_probe = nullptr;   // set (under mu) by a plan created with QLDPC_FLAG_CLOCK_PROBE around one launch
 };

@@ -32,7 +32,7 @@ bool inputs_clean(const double *prior, int n, double clip, const double *alpha, 
     return true;
 }
 
-int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
+static int dispatch_kernel(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
                            const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
                            uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
     const bool want_stream = flags & QLDPC_FLAG_KERNEL_STREAM;
@@ -50,6 +50,17 @@ int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     if (!want_stream && wg_supported(g, damping))
         return minsum_wg_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
     return minsum_stream_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
+}
+
+// callers hold g->mu; the graph's device workspaces are handed over in stream order (common.h)
+int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
+                           const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
+                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
+    int rc = g->ws_acquire(stream);
+    if (rc != QLDPC_OK) return rc;
+    rc = dispatch_kernel(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
+    if (rc != QLDPC_OK) return rc;
+    return g->ws_release(stream);
 }
 
 }  // namespace qldpc
@@ -76,23 +87,18 @@ static int decode_dev_impl(const qldpc_graph *g, int64_t B, const int8_t *d_synd
                                                double *d_llr, uint8_t *d_conv, int32_t *d_iter, void *stream) {
     int rc = check_decode_args(g, B, d_synd, d_prior, max_iter, clip_llr, d_err, d_llr, d_conv, d_iter);
     if (rc != QLDPC_OK) return rc;
-    if ((rc = use_device(g->device)) != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
     if (B == 0) return QLDPC_OK;
     std::vector<double> tab;
     if ((rc = build_alpha_table(max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, tab)) != QLDPC_OK) return rc;
     std::lock_guard<std::mutex> lk(g->mu);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (tab != g->alpha_host) {               // the table on the device is reused while the alpha schedule does not change
-        if ((rc = g->ws_alpha.ensure(tab.size() * sizeof(double))) != QLDPC_OK) return rc;
-        QLDPC_HIP_TRY(hipDeviceSynchronize());    // a decode (on any stream) still reading the old table must finish first
-        QLDPC_HIP_TRY(hipMemcpyAsync(g->ws_alpha.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
-        QLDPC_HIP_TRY(hipStreamSynchronize(s));   // tab is a stack temporary: the copy must have left host memory
-        g->alpha_host = tab;
-    }
+    const double *d_alpha = nullptr;          // per-graph cache of alpha tables: a new schedule is uploaded once, nothing synchronises
+    if ((rc = g->alpha_table(tab, s, &d_alpha)) != QLDPC_OK) return rc;
     // prior_finite here means "host-verified clean prior" (finite, no -0.0); clip and alphas are checked the same way
     bool nanfree = prior_finite && std::isfinite(damping) && inputs_clean(nullptr, 0, clip_llr, tab.data(), max_iter);
     flags = (flags & 0xFFFF) | (prior_finite ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0);
-    return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, g->ws_alpha.as<double>(), damping, clip_llr, flags, nanfree, d_err,
+    return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip_llr, flags, nanfree, d_err,
                                   d_llr, d_conv, d_iter, s);
 }
 
@@ -112,7 +118,7 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, cons
     // out_llr may be NULL: the posteriors (8n of the 9n + 5 result bytes per shot) then stay on the device
     int rc = check_decode_args(g, B, syndromes, prior, max_iter, clip_llr, out_err, out_llr ? (const void *)out_llr : (const void *)out_err, out_conv, out_iter);
     if (rc != QLDPC_OK) return rc;
-    if ((rc = use_device(g->device)) != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
     if (B == 0) return QLDPC_OK;
     const size_t m = g->m, n = g->n;
     // One grow-only device slab per graph handle (no hipMalloc / hipFree per call: the reference-style single-shot call is

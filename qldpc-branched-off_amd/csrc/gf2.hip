@@ -8,6 +8,7 @@
 // one at/below `row`), so XOR-ing words >= pivot_col/64 reproduces the reference's full-row XOR bit for bit.
 #include "common.h"
 #include "mc_common.h"
+#include "osd_common.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -193,17 +194,27 @@ __global__ __launch_bounds__(1024) void osd0_kernel(OsdArgs P) {
 }
 
 int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled);
+                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
 
+static int osd0_global_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+                              const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream);
+
+// callers hold g->mu; the graph's device workspaces are handed over in stream order (common.h)
 int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream) {
+                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream) {
+    if (g->m == 0 || g->n == 0) return QLDPC_OK;
+    int rc = g->ws_acquire(stream);
+    if (rc != QLDPC_OK) return rc;
+    bool handled = false;           // LDS-resident kernels for m <= 4096; the global-memory kernel is the general fallback
+    rc = osd0_lds_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
+    if (rc == QLDPC_OK && !handled) rc = osd0_global_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, stream);
+    if (rc != QLDPC_OK) return rc;
+    return g->ws_release(stream);
+}
+
+static int osd0_global_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+                              const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream) {
     const int m = g->m, n = g->n;
-    if (m == 0 || n == 0) return QLDPC_OK;
-    {
-        bool handled = false;           // LDS-resident kernel for m <= 1024; the global-memory kernel below is the general fallback
-        const int rc0 = osd0_lds_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, stream, handled);
-        if (rc0 != QLDPC_OK || handled) return rc0;
-    }
     const int nwords = ((n + 7) / 8 + 7) / 8;
     const int maxp = m < n ? m : n;
     const size_t slab = (size_t)m * nwords * 8 + (size_t)m + (size_t)n * 8 + (size_t)maxp * 8 + (size_t)n * 8 + 64;
@@ -442,8 +453,8 @@ QLDPC_EXPORT int qldpc_gf2_eliminate_packed(int64_t B, int m, int n, int nwords,
                                             int64_t *pivot_cols, int32_t *num_pivots) {
     QLDPC_REQUIRE(B >= 0 && m >= 0 && n >= 0, "negative size");
     QLDPC_REQUIRE(nwords * 64 >= n, "nwords=%d too small for n=%d", nwords, n);
-    int rc = use_device(0);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(0);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0) return QLDPC_OK;
     QLDPC_REQUIRE(num_pivots != nullptr, "num_pivots is NULL");
     if (m == 0 || n == 0) { for (int64_t i = 0; i < B; i++) num_pivots[i] = 0; return QLDPC_OK; }
@@ -476,8 +487,8 @@ QLDPC_EXPORT int qldpc_gf2_eliminate_packed(int64_t B, int m, int n, int nwords,
 QLDPC_EXPORT int qldpc_gf2_eliminate(int64_t B, int m, int n, uint8_t *A, uint8_t *b, int64_t *pivot_rows, int64_t *pivot_cols,
                                      int32_t *num_pivots) {
     QLDPC_REQUIRE(B >= 0 && m >= 0 && n >= 0, "negative size");
-    int rc = use_device(0);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(0);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0) return QLDPC_OK;
     QLDPC_REQUIRE(num_pivots != nullptr, "num_pivots is NULL");
     if (m == 0 || n == 0) { for (int64_t i = 0; i < B; i++) num_pivots[i] = 0; return QLDPC_OK; }
@@ -511,11 +522,11 @@ QLDPC_EXPORT int qldpc_gf2_eliminate(int64_t B, int m, int n, uint8_t *A, uint8_
 }
 
 QLDPC_EXPORT int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, const double *llr, const int8_t *hard,
-                                  const int32_t *ordering, int8_t *solution) {
+                                  const int32_t *ordering, int flags, int8_t *solution) {
     QLDPC_REQUIRE(g != nullptr, "graph is NULL");
     QLDPC_REQUIRE(B >= 0 && B < ((int64_t)1 << 31), "batch out of range");
-    int rc = use_device(g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0 || g->n == 0) return QLDPC_OK;
     QLDPC_REQUIRE(llr && hard && solution && (syndromes || g->m == 0), "NULL buffer");
     const size_t m = g->m, n = g->n;
@@ -532,7 +543,7 @@ QLDPC_EXPORT int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t 
     {
         std::lock_guard<std::mutex> lk(g->mu);
         rc = osd0_listed_launch(g, dlist.as<int32_t>(), dcnt.as<int32_t>(), ds.as<int8_t>(), dl.as<double>(), dh.as<int8_t>(),
-                                ordering ? dord.as<int32_t>() : nullptr, dsol.as<int8_t>(), nullptr);
+                                ordering ? dord.as<int32_t>() : nullptr, dsol.as<int8_t>(), flags, nullptr);
         if (rc == QLDPC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("OSD-0 kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = QLDPC_ERR_HIP; }
     }
     if (rc != QLDPC_OK) return rc;
@@ -543,13 +554,13 @@ QLDPC_EXPORT int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t 
 // device-pointer form of qldpc_osd0_batch: only enqueues on `stream`.  d_select (may be NULL = every shot) lists the shots to solve, e.g. the
 // ones a decode left unconverged; *d_select_count is read on the device, so no host round trip is needed between decode and OSD-0.
 QLDPC_EXPORT int qldpc_osd0_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_syndromes, const double *d_llr, const int8_t *d_hard,
-                                      const int32_t *d_ordering, const int32_t *d_select, const int32_t *d_select_count, int8_t *d_solution,
-                                      void *stream) {
+                                      const int32_t *d_ordering, const int32_t *d_select, const int32_t *d_select_count, int flags,
+                                      int8_t *d_solution, void *stream) {
     QLDPC_REQUIRE(g != nullptr, "graph is NULL");
     QLDPC_REQUIRE(B >= 0 && B < ((int64_t)1 << 31), "batch out of range");
     QLDPC_REQUIRE((d_select == nullptr) == (d_select_count == nullptr), "d_select and d_select_count go together");
-    int rc = use_device(g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0 || g->n == 0) return QLDPC_OK;
     QLDPC_REQUIRE(d_llr && d_hard && d_solution && (d_syndromes || g->m == 0), "NULL buffer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -560,7 +571,7 @@ QLDPC_EXPORT int qldpc_osd0_batch_dev(const qldpc_graph *g, int64_t B, const int
         hipLaunchKernelGGL(iota_list_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, list, cnt);
         d_select = list; d_select_count = cnt;
     }
-    return osd0_listed_launch(g, d_select, d_select_count, d_syndromes, d_llr, d_hard, d_ordering, d_solution, s);
+    return osd0_listed_launch(g, d_select, d_select_count, d_syndromes, d_llr, d_hard, d_ordering, d_solution, flags, s);
 }
 
 // f1: batched performOSD_enhanced(order, max_combinations) (osd.py:5-77); order == 0 is qldpc_osd0_batch.
@@ -568,11 +579,11 @@ QLDPC_EXPORT int qldpc_osdw_batch(const qldpc_graph *g, int64_t B, const int8_t 
                                   const int32_t *ordering, int order, int64_t max_combinations, int8_t *solution) {
     QLDPC_REQUIRE(g != nullptr, "graph is NULL");
     QLDPC_REQUIRE(order >= 0, "order must be >= 0");
-    if (order == 0) return qldpc_osd0_batch(g, B, syndromes, llr, hard, ordering, solution);
+    if (order == 0) return qldpc_osd0_batch(g, B, syndromes, llr, hard, ordering, 0, solution);
     QLDPC_REQUIRE(B >= 0 && B < ((int64_t)1 << 31), "batch out of range");
     QLDPC_REQUIRE(order <= kOsdwMaxOrder, "OSD order %d above the supported maximum %d", order, kOsdwMaxOrder);
-    int rc = use_device(g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0 || g->n == 0) return QLDPC_OK;
     QLDPC_REQUIRE(llr && hard && solution && (syndromes || g->m == 0), "NULL buffer");
     const int m = g->m, n = g->n;
@@ -655,6 +666,7 @@ struct OsdLdsArgs {
     unsigned long long *ug;        // UG kernels: [grid][(m + 2) * mw] row transform in HBM/L2, followed by [grid][n] sort keys
     unsigned long long *ugkeys;
     int *queue;                    // next list entry to process (zeroed before the launch): work is handed out one shot at a time
+    unsigned long long *clk;       // QLDPC_FLAG_CLOCK_PROBE buffer of the launching plan, else NULL
     unsigned long long *dbg;       // optional counters: [0] shots, [1] chunks, [2] columns swept, [3] pivots, [4] cycles, [5] kill passes, [6] blocks
     int offIdx, offAlive, offRows, offPc, offR, offBlk, offMisc, offSort;
 };
@@ -699,6 +711,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     const int brow = m + 1;                                                // U row that carries b
 
     const int total = *P.count;
+    const ClkStamp clk0 = clk_begin(P.clk);
     int *s_item = reinterpret_cast<int *>(stp + kOsdBlock);                  // the list entry this workgroup processes next
     for (;;) {
         if (tid == 0) *s_item = atomicAdd(P.queue, 1);
@@ -709,7 +722,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         const double *llr = P.llr + shot * n;
         const int8_t *hard = P.hard + shot * n, *synd = P.synd + shot * m;
         int8_t *sol = P.solution + shot * n;
-        const long long t_start = clock64();
+        const long long t_start = OSD_CLOCK();
         // ---- column order: ascending |llr| (osd.py:11-12), ties by ascending index; bitonic sort of (key, index) in LDS ----
         if (!P.ordering) {
             // Stable LSD radix sort of the column indices by the 64-bit key, 8 passes of 8 bits (a bitonic network of (key, index)
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         __syncthreads();
         int row = 0;
         unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0;
-        const long long t_sorted = clock64();
+        const long long t_sorted = OSD_CLOCK();
         bool finished = (P.rankH == 0);
         for (int base = 0; base < n && !finished; base += K) {
             const int L = min(K, n - base);
@@ -877,11 +890,11 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 }
             };
             if (row > 0 && !P.nokill) {                                      // a fresh chunk late in the sweep is mostly dependent columns: one pass up
-                long long tk = clock64();                                    // front instead of one serial pivot step per dependent column
+                long long tk = OSD_CLOCK();                                    // front instead of one serial pivot step per dependent column
                 d_kills++;
                 kill_pass(0);
                 __syncthreads();
-                c_kill += clock64() - tk;
+                c_kill += OSD_CLOCK() - tk;
             }
             // ================= blocks of up to kOsdBlock alive columns =================
             while (true) {
@@ -909,7 +922,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 const int nb = blk[0];
                 if (nb == 0) break;
                 d_blocks++; d_cols += nb;
-                long long tp = clock64();
+                long long tp = OSD_CLOCK();
                 // ---- phase 1: reduced columns R[t] = XOR of U rows ----
                 for (int x = tid; x < nb * mw; x += T) {
                     const int t = x / mw, w = x - t * mw;
@@ -925,7 +938,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     R[t * mw + w] = acc;
                 }
                 __syncthreads();
-                c_p1 += clock64() - tp; tp = clock64();
+                c_p1 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
                 // ---- phase 2: the block's pivots.  Waves 0-3 (one per SIMD) hold 4 columns each: lane = (grp, w) has word w of column
                 // 4*wave + grp.  Column t's owner finds its pivot (first set bit at a position >= lrow, kernels.py:71-75), turns the
                 // column into the elimination mask and publishes (a, pp); after ONE barrier the waves holding later columns apply that
@@ -986,7 +999,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     }
                 }
                 __syncthreads();
-                c_p2 += clock64() - tp; tp = clock64();
+                c_p2 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
                 // ---- phase 3: apply the block's operations to every row of U (and to b) ----
                 for (int q = tid; q < m + 2; q += T) {
                     if (q == m) continue;
@@ -1024,21 +1037,21 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 }
                 row += nops;
                 __syncthreads();
-                c_p3 += clock64() - tp; tp = clock64();
+                c_p3 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
                 if (row >= P.rankH || row >= m) { finished = true; break; }
                 // ---- dependent columns were met: drop every column of the chunk that is dependent by now ----
                 if (anydep && !P.nokill) {
                     d_kills++;
                     kill_pass(blk[3]);
                     __syncthreads();
-                    c_kill += clock64() - tp;
+                    c_kill += OSD_CLOCK() - tp;
                 }
             }
             __syncthreads();      // nobody may refill alive[]/sidx[] while others still use them
         }
         if (P.dbg && tid == 0) {
             atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)row);
-            atomicAdd(&P.dbg[4], (unsigned long long)(clock64() - t_start)); atomicAdd(&P.dbg[5], d_kills); atomicAdd(&P.dbg[6], d_blocks);
+            atomicAdd(&P.dbg[4], (unsigned long long)(OSD_CLOCK() - t_start)); atomicAdd(&P.dbg[5], d_kills); atomicAdd(&P.dbg[6], d_blocks);
             atomicAdd(&P.dbg[8], (unsigned long long)(t_sorted - t_start)); atomicAdd(&P.dbg[9], c_p1); atomicAdd(&P.dbg[10], c_p2); atomicAdd(&P.dbg[11], c_p3);
             atomicAdd(&P.dbg[12], c_kill);
         }
@@ -1053,6 +1066,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         }
         __syncthreads();
     }
+    clk_end(P.clk, clk0);
 }
 
 // rank of H over GF(2) (host, once per graph): the sweep above can stop as soon as this many pivots exist
@@ -1077,12 +1091,12 @@ static int host_rank(const qldpc_graph *g) {
 }
 
 // 0: not applicable (use the global-memory elimination), 1: U in LDS (m <= 1024), 2: U in HBM/L2 (m <= 4096, "UG")
-static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
+static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds, int flags) {
     if (g->m > 4096 || g->n >= 65535 || g->m < 1) return 0;
     P.m = g->m; P.n = g->n; P.mw = (g->m + 63) / 64; P.K = 1024; P.cdeg = std::max(g->max_col_deg, 1);
     P.npad = 1;
     while (P.npad < g->n) P.npad <<= 1;
-    for (int mode = (g->m <= 1024 && !getenv("QLDPC_OSD_UG")) ? 1 : 2; mode <= 2; mode++) {
+    for (int mode = (g->m <= 1024 && !(flags & QLDPC_FLAG_OSD_UG)) ? 1 : 2; mode <= 2; mode++) {
         const size_t sort_cnt = (size_t)256 * 16 * 4 + 16 * 4 + 64;                         // [256][waves] radix counters + per-wave sums
         size_t off = (mode == 1) ? std::max((size_t)(g->m + 2) * P.mw * 8, (size_t)g->n * 12 + 16 + sort_cnt) : 0;     // U, aliased by the sort scratch
         off = (size_t)round_up((int64_t)off, 16);
@@ -1101,11 +1115,11 @@ static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds) {
 }
 
 int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled) {
+                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled) {
     OsdLdsArgs P;
     size_t lds = 0;
     handled = false;
-    const int mode = getenv("QLDPC_OSD_GLOBAL") ? 0 : plan_osd_lds(g, P, lds);
+    const int mode = (flags & QLDPC_FLAG_OSD_GLOBAL) ? 0 : plan_osd_lds(g, P, lds, flags);
     if (mode == 0) return QLDPC_OK;
     if (g->gf2_rank < 0) g->gf2_rank = host_rank(g);      // callers hold g->mu
     P.rankH = g->gf2_rank;
@@ -1121,30 +1135,15 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     P.ugkeys = reinterpret_cast<unsigned long long *>(g->ws_misc.as<unsigned char>() + sz_ord + sz_u);
     P.indptr = g->d_indptr; P.indices = g->d_indices; P.colptr = g->d_colptr; P.rowidx = g->d_rowidx;
     P.list = d_list; P.count = d_count; P.synd = d_synd; P.llr = d_llr; P.hard = d_hard; P.ordering = d_ordering; P.solution = d_solution;
-    static unsigned long long *d_dbg = nullptr;
-    P.dbg = nullptr;
-    if (getenv("QLDPC_OSD_DEBUG")) {
-        if (!d_dbg) { QLDPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_dbg), 128)); QLDPC_HIP_TRY(hipMemset(d_dbg, 0, 128)); }
-        else {
-            unsigned long long h[16];
-            QLDPC_HIP_TRY(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));      // counters of the previous launches
-            if (h[0]) fprintf(stderr, "[osd dbg] shots=%llu chunks/shot=%.2f cols/shot=%.1f pivots/shot=%.1f kills/shot=%.1f blocks/shot=%.1f kcycles/shot=%.1f (sort %.0f p1 %.0f p2 %.0f p3 %.0f kill %.0f) rankH=%d\n",
-                              h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[4] / h[0] / 1e3,
-                              (double)h[8] / h[0] / 1e3, (double)h[9] / h[0] / 1e3, (double)h[10] / h[0] / 1e3, (double)h[11] / h[0] / 1e3, (double)h[12] / h[0] / 1e3, g->gf2_rank);
-        }
-        P.dbg = d_dbg;
-    }
-    P.nokill = getenv("QLDPC_OSD_NOKILL") ? 1 : 0;
+    P.clk = g->clk_probe;
+    P.dbg = osd_timer_buffer();      // NULL unless built with -DQLDPC_OSD_TIMERS (make timers)
+    P.nokill = (flags & QLDPC_FLAG_OSD_NOKILL) ? 1 : 0;
     const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m + 2, 256), 64));
     if ((rc = g->ws_queue.ensure(16)) != QLDPC_OK) return rc;
     P.queue = g->ws_queue.as<int>() + 2;
     QLDPC_HIP_TRY(hipMemsetAsync(P.queue, 0, 4, stream));
-    static bool attr = false;
-    if (!attr) {
-        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(osd0_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    if ((rc = ensure_max_lds(g->device, reinterpret_cast<const void *>(osd0_lds_kernel<false>), 160 * 1024)) != QLDPC_OK) return rc;
+    if ((rc = ensure_max_lds(g->device, reinterpret_cast<const void *>(osd0_lds_kernel<true>), 160 * 1024)) != QLDPC_OK) return rc;
     if (mode == 2) hipLaunchKernelGGL(osd0_lds_kernel<true>, dim3(grid), dim3(1024), lds, stream, P);
     else hipLaunchKernelGGL(osd0_lds_kernel<false>, dim3(grid), dim3(block), lds, stream, P);
     QLDPC_HIP_TRY(hipGetLastError());
@@ -1153,3 +1152,35 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
 }
 
 }  // namespace qldpc
+
+// ---- diagnostic phase counters (see osd_common.h) ----
+namespace qldpc {
+unsigned long long *osd_timer_buffer() {
+#ifdef QLDPC_OSD_TIMERS
+    static std::mutex mu;
+    static unsigned long long *d_buf[64] = {nullptr};
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!d_buf[dev]) {
+        if (hipMalloc(reinterpret_cast<void **>(&d_buf[dev]), 16 * 8) != hipSuccess) { d_buf[dev] = nullptr; return nullptr; }
+        (void)hipMemset(d_buf[dev], 0, 16 * 8);
+    }
+    return d_buf[dev];
+#else
+    return nullptr;
+#endif
+}
+}  // namespace qldpc
+
+// Phase counters of the OSD-0 kernels accumulated on the CURRENT device since the last reset (uint64[16], layout in osd_common.h).
+// Only the diagnostic build (make timers) counts; the default build returns QLDPC_ERR_UNSUPPORTED.  Synchronises the device.
+QLDPC_EXPORT int qldpc_osd_timers_read(uint64_t *out, int reset) {
+    QLDPC_REQUIRE(out != nullptr, "out is NULL");
+    unsigned long long *d = qldpc::osd_timer_buffer();
+    if (!d) { qldpc::set_error("OSD phase timers are compiled out of this build (make -C csrc timers)"); return QLDPC_ERR_UNSUPPORTED; }
+    QLDPC_HIP_TRY(hipDeviceSynchronize());
+    QLDPC_HIP_TRY(hipMemcpy(out, d, 16 * 8, hipMemcpyDeviceToHost));
+    if (reset) QLDPC_HIP_TRY(hipMemset(d, 0, 16 * 8));
+    return QLDPC_OK;
+}

@@ -37,6 +37,36 @@ int use_device(int device) {
     return QLDPC_OK;
 }
 
+int DeviceScope::enter(int device) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+    const int rc = use_device(device);
+    if (rc == QLDPC_OK && cur >= 0 && cur != device) prev = cur;
+    return rc;
+}
+DeviceScope::~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+int ensure_max_lds(int device, const void *func, int bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void *>> done;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto &d : done) if (d.first == device && d.second == func) return QLDPC_OK;
+    QLDPC_HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.emplace_back(device, func);
+    return QLDPC_OK;
+}
+
+double clock_probe_median(const unsigned long long *pairs, int slots) {
+    std::vector<double> v;
+    for (int i = 0; i < slots; i++)
+        if (pairs[2 * i + 1] > 0) v.push_back(100.0 * (double)pairs[2 * i] / (double)pairs[2 * i + 1]);
+    if (v.empty()) return 0.0;
+    std::sort(v.begin(), v.end());
+    return v[v.size() / 2];
+}
+
 int DevBuf::ensure(size_t bytes) {
     if (bytes <= cap && p) return QLDPC_OK;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
@@ -60,6 +90,44 @@ void DevBuf::release() {
 }  // namespace qldpc
 
 using namespace qldpc;
+
+int qldpc_graph::ws_acquire(hipStream_t stream) const {
+    if (ws_used && stream != ws_stream && ws_event) QLDPC_HIP_TRY(hipStreamWaitEvent(stream, ws_event, 0));
+    return QLDPC_OK;
+}
+int qldpc_graph::ws_release(hipStream_t stream) const {
+    if (!ws_event) QLDPC_HIP_TRY(hipEventCreateWithFlags(&ws_event, hipEventDisableTiming));
+    QLDPC_HIP_TRY(hipEventRecord(ws_event, stream));
+    ws_stream = stream; ws_used = true;
+    return QLDPC_OK;
+}
+
+int qldpc_graph::alpha_table(const std::vector<double> &tab, hipStream_t stream, const double **d_out) const {
+    for (const AlphaEntry &e : alpha_cache)
+        if (e.host == tab) {
+            if (stream != e.stream) QLDPC_HIP_TRY(hipStreamWaitEvent(stream, e.ready, 0));   // uploaded on another stream: order behind it
+            *d_out = e.dev;
+            return QLDPC_OK;
+        }
+    if (alpha_cache.size() >= 64) {            // a caller cycling through > 64 schedules: start over once everything in flight is done
+        QLDPC_HIP_TRY(hipDeviceSynchronize());
+        for (AlphaEntry &e : alpha_cache) { if (e.dev) (void)hipFree(e.dev); if (e.pinned) (void)hipHostFree(e.pinned); if (e.ready) (void)hipEventDestroy(e.ready); }
+        alpha_cache.clear();
+    }
+    AlphaEntry e;
+    e.host = tab;
+    const size_t bytes = std::max<size_t>(tab.size(), 1) * sizeof(double);
+    QLDPC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e.pinned), bytes, hipHostMallocDefault));
+    std::memcpy(e.pinned, tab.data(), tab.size() * sizeof(double));
+    if (hipMalloc(reinterpret_cast<void **>(&e.dev), bytes) != hipSuccess) { (void)hipHostFree(e.pinned); set_error("hipMalloc failed for an alpha table"); return QLDPC_ERR_HIP; }
+    QLDPC_HIP_TRY(hipMemcpyAsync(e.dev, e.pinned, tab.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    QLDPC_HIP_TRY(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
+    QLDPC_HIP_TRY(hipEventRecord(e.ready, stream));
+    e.stream = stream;
+    alpha_cache.push_back(e);
+    *d_out = e.dev;
+    return QLDPC_OK;
+}
 
 QLDPC_EXPORT const char *qldpc_last_error(void) { return g_last_error.c_str(); }
 QLDPC_EXPORT int qldpc_version(void) { return 100; }
@@ -147,7 +215,9 @@ QLDPC_EXPORT void qldpc_graph_destroy(qldpc_graph *g) {
         if (p) (void)hipFree(p);
     if (g->d_ell_col) (void)hipFree(g->d_ell_col);
     if (g->d_ell_var) (void)hipFree(g->d_ell_var);
-    g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_alpha.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_list.release();
+    g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_list.release();
+    for (auto &e : g->alpha_cache) { if (e.dev) (void)hipFree(e.dev); if (e.pinned) (void)hipHostFree(e.pinned); if (e.ready) (void)hipEventDestroy(e.ready); }
+    if (g->ws_event) (void)hipEventDestroy(g->ws_event);
     if (g->pin) (void)hipHostFree(g->pin);
     delete g;
 }

@@ -121,7 +121,7 @@ struct qldpc_cc_plan {
     uint32_t thr = 0;
     int64_t batch = 0;
     std::vector<double> alpha;
-    DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol, d_cold;
+    DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol, d_cold, d_clk;
     bool fused = false, nanfree = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decode-kernel brackets not yet read
@@ -148,8 +148,8 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
     QLDPC_REQUIRE(p > 0.0 && p < 1.0, "error rate must be in (0,1)");
     QLDPC_REQUIRE(batch > 0 && batch <= ((int64_t)1 << 30), "batch out of range");
     QLDPC_REQUIRE(max_iter >= 0, "negative max_iter");
-    int rc = use_device(g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
+    int rc = QLDPC_OK; (void)rc;
     qldpc_cc_plan *P = new qldpc_cc_plan();
     P->g = g; P->k = k; P->max_iter = max_iter; P->use_osd = use_osd; P->flags = flags;
     P->p = p; P->damping = damping; P->clip = clip_llr; P->batch = batch;
@@ -183,8 +183,13 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
     }
     if (P->fused) {
         if ((rc = P->d_cold.ensure(mc_regular_cold_bytes())) != QLDPC_OK) return fail(rc);
+        if (flags & QLDPC_FLAG_CLOCK_PROBE) {
+            if ((rc = P->d_clk.ensure(2 * kClkSlots * 8)) != QLDPC_OK) return fail(rc);
+            if (hipMemset(P->d_clk.p, 0, 2 * kClkSlots * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
+        }
         if ((rc = mc_regular_fill_cold(P->d_cold.p, P->d_tally.as<unsigned long long>(), P->d_count.as<int32_t>(), P->d_list.as<int32_t>(),
-                                       P->d_synd.as<int8_t>(), P->d_err.as<int8_t>(), P->d_dec.as<int8_t>(), P->d_llr.as<double>())) != QLDPC_OK)
+                                       P->d_synd.as<int8_t>(), P->d_err.as<int8_t>(), P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
+                                       (flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() : nullptr)) != QLDPC_OK)
             return fail(rc);
     }
     *out = P;
@@ -194,8 +199,8 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
 QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot_begin, int64_t count, void *stream) {
     QLDPC_REQUIRE(P != nullptr, "plan is NULL");
     QLDPC_REQUIRE(count >= 0 && shot_begin >= 0, "negative shot range");
-    int rc = use_device(P->g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(P->g->device);
+    int rc = QLDPC_OK; (void)rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const qldpc_graph *g = P->g;
     const int n = g->n, m = g->m;
@@ -214,7 +219,7 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
             if (P->use_osd) {
                 std::lock_guard<std::mutex> lk(g->mu);
                 if ((rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), P->d_synd.as<int8_t>(), P->d_llr.as<double>(),
-                                             P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), s)) != QLDPC_OK)
+                                             P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), P->flags, s)) != QLDPC_OK)
                     return rc;
                 if ((rc = judge_failed_launch(g, P->d_count.as<int32_t>(), P->d_Lmask.as<uint64_t>(), P->d_err.as<int8_t>(), P->d_synd.as<int8_t>(),
                                               P->d_dec.as<int8_t>(), P->d_tally.as<unsigned long long>(), s)) != QLDPC_OK)
@@ -246,7 +251,7 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
             {
                 std::lock_guard<std::mutex> lk(g->mu);
                 rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), P->d_synd.as<int8_t>(), P->d_llr.as<double>(),
-                                        P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), s);
+                                        P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), P->flags, s);
             }
             if (rc != QLDPC_OK) return rc;
             hipLaunchKernelGGL(add_osd_count_kernel, dim3(1), dim3(64), 0, s, P->d_count.as<int32_t>(),
@@ -274,8 +279,8 @@ static int drain_events(qldpc_cc_plan *P) {
 
 QLDPC_EXPORT int qldpc_cc_plan_read(qldpc_cc_plan *P, void *stream, int clear, int64_t *tally) {
     QLDPC_REQUIRE(P != nullptr && tally != nullptr, "NULL argument");
-    int rc = use_device(P->g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(P->g->device);
+    int rc = QLDPC_OK; (void)rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     QLDPC_HIP_TRY(hipStreamSynchronize(s));
     QLDPC_HIP_TRY(hipMemcpy(tally, P->d_tally.p, QLDPC_TALLY_SLOTS * 8, hipMemcpyDeviceToHost));
@@ -293,13 +298,24 @@ QLDPC_EXPORT int qldpc_cc_plan_kernel_time(qldpc_cc_plan *P, double *ms_total, i
     return QLDPC_OK;
 }
 
+QLDPC_EXPORT int qldpc_cc_plan_clock(qldpc_cc_plan *P, void *stream, double *mhz) {
+    QLDPC_REQUIRE(P != nullptr && mhz != nullptr, "NULL argument");
+    QLDPC_REQUIRE((P->flags & QLDPC_FLAG_CLOCK_PROBE) && P->fused, "the plan was created without QLDPC_FLAG_CLOCK_PROBE (or does not use the fused kernel)");
+    QLDPC_USE_DEVICE(P->g->device);
+    QLDPC_HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    std::vector<unsigned long long> h(2 * kClkSlots);
+    QLDPC_HIP_TRY(hipMemcpy(h.data(), P->d_clk.p, h.size() * 8, hipMemcpyDeviceToHost));
+    *mhz = clock_probe_median(h.data(), kClkSlots);
+    return QLDPC_OK;
+}
+
 QLDPC_EXPORT void qldpc_cc_plan_destroy(qldpc_cc_plan *P) {
     if (!P) return;
     (void)hipSetDevice(P->g->device);
     for (auto &pr : P->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : P->pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&P->d_alpha, &P->d_prior, &P->d_Lmask, &P->d_err, &P->d_synd, &P->d_dec, &P->d_llr, &P->d_conv, &P->d_iter,
-                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol, &P->d_cold})
+                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol, &P->d_cold, &P->d_clk})
         b->release();
     delete P;
 }
@@ -324,8 +340,8 @@ QLDPC_EXPORT int qldpc_cc_sample_decode_tally(const qldpc_graph *g, int k, const
 QLDPC_EXPORT int qldpc_gf2_spmv_batch(const qldpc_graph *g, int64_t B, const int8_t *vectors, int8_t *out) {
     QLDPC_REQUIRE(g != nullptr, "graph is NULL");
     QLDPC_REQUIRE(B >= 0, "negative batch");
-    int rc = use_device(g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0 || g->m == 0) return QLDPC_OK;
     QLDPC_REQUIRE(vectors != nullptr && out != nullptr, "NULL buffer");
     DevTmp dv, dout;
@@ -341,8 +357,8 @@ QLDPC_EXPORT int qldpc_gf2_spmv_batch(const qldpc_graph *g, int64_t B, const int
 QLDPC_EXPORT int qldpc_gf2_spmv_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_vectors, int8_t *d_out, void *stream) {
     QLDPC_REQUIRE(g != nullptr, "graph is NULL");
     QLDPC_REQUIRE(B >= 0, "negative batch");
-    int rc = use_device(g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0 || g->m == 0) return QLDPC_OK;
     QLDPC_REQUIRE(d_vectors != nullptr && d_out != nullptr, "NULL buffer");
     return gf2_spmv_launch(g, B, d_vectors, d_out, reinterpret_cast<hipStream_t>(stream));

@@ -39,6 +39,6 @@ int gf2_spmv_launch(const qldpc_graph *g, int64_t B, const int8_t *d_vec, int8_t
 // OSD-0 on the shots listed in d_list[0 .. *d_count) (device-resident count: no host sync).  d_ordering may be NULL
 // (stable ascending |llr|); otherwise int32[B][n] indexed by shot.  solution may alias hard.
 int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream);
+                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream);
 
 }  // namespace qldpc

@@ -50,7 +50,7 @@ int mc_regular_launch(const qldpc_graph *g, int64_t B, const double *d_prior, in
                       bool nanfree, uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask,
                       void *d_cold, hipStream_t stream);
 int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd,
-                         int8_t *f_err, int8_t *f_hard, double *f_llr);
+                         int8_t *f_err, int8_t *f_hard, double *f_llr, unsigned long long *d_clk);
 size_t mc_regular_cold_bytes();
 int judge_failed_launch(const qldpc_graph *g, const int32_t *d_count, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
                         const int8_t *f_dec, unsigned long long *d_tally, hipStream_t stream);

@@ -43,6 +43,7 @@ struct RegArgs {
 struct RegCold {
     unsigned long long *tally;
     int32_t *fail_count, *fail_list; int8_t *f_synd, *f_err, *f_hard; double *f_llr;
+    unsigned long long *clk;        // QLDPC_FLAG_CLOCK_PROBE: per-workgroup (delta s_memtime, delta s_memrealtime), else NULL
 };
 
 // v_min_f64 / v_max_f64 without the canonicalising v_max the compiler adds around fmin()/fmax() (operands here are
@@ -105,6 +106,8 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
     const double clip = A.clip, nclip = -A.clip, damping = A.damping, one_minus_d = 1.0 - A.damping;
     for (int k = threadIdx.x; k < max_iter; k += blockDim.x) reinterpret_cast<double *>(lds + A.offA)[k] = A.alpha[k];
     if (MC && threadIdx.x < 6) Tl[threadIdx.x] = 0ull;
+    unsigned long long *clkbuf = MC ? A.cold->clk : nullptr;
+    const ClkStamp clk0 = clk_begin(clkbuf);
 
     // ---- per-thread graph slices (registers, loaded once) ----
     const bool has_check = in_team && member < m;
@@ -322,6 +325,7 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
             __syncthreads();
         }
     }
+    if (MC) clk_end(clkbuf, clk0);
     if (MC && threadIdx.x < 6 && Tl[threadIdx.x]) {
         unsigned long long *tally = A.cold->tally;
         const unsigned long long v = Tl[threadIdx.x];
@@ -377,7 +381,6 @@ static bool plan_regular(const qldpc_graph *g, int max_iter, RegPlan &P) {
     const int rst = (cdeg % 2 == 0) ? cdeg + 1 : cdeg;
     const int nq = (g->n + 3) / 4;
     int S = QLDPC_LB_T / ts;                           // 4 blocks per CU fill its 32 wave slots
-    if (const char *ov = getenv("QLDPC_RES_S")) { const int v = atoi(ov); if (v >= 1 && v * ts <= QLDPC_LB_T) S = v; }
     auto layout = [&](int s) {
         P.offV = s * g->m * rst * 8;
         P.offE = P.offV + s * g->n * 8;
@@ -468,8 +471,8 @@ int mc_regular_launch(const qldpc_graph *g, int64_t B, const double *d_prior, in
 
 // Fills the device-resident cold-argument block of a Monte-Carlo plan (done once per plan).
 int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd,
-                         int8_t *f_err, int8_t *f_hard, double *f_llr) {
-    RegCold C{d_tally, d_fail_count, d_fail_list, f_synd, f_err, f_hard, f_llr};
+                         int8_t *f_err, int8_t *f_hard, double *f_llr, unsigned long long *d_clk) {
+    RegCold C{d_tally, d_fail_count, d_fail_list, f_synd, f_err, f_hard, f_llr, d_clk};
     QLDPC_HIP_TRY(hipMemcpy(d_cold, &C, sizeof(C), hipMemcpyHostToDevice));
     return QLDPC_OK;
 }

@@ -234,10 +234,6 @@ static bool plan_resident(const qldpc_graph *g, ResidentPlan &P) {
     const size_t lds_budget = 64 * 1024;   // two workgroups per CU
     while (S > 1 && (size_t)S * per_slot + 16 > lds_budget) S--;
     if (S < 1) return false;
-    if (const char *ov = getenv("QLDPC_RES_S")) {          // tuning override (experiments only)
-        const int v = atoi(ov);
-        if (v >= 1 && v * ts <= 1024 && (size_t)v * per_slot + 16 <= 150 * 1024) S = v;
-    }
     P.S = S;
     P.lds = (size_t)S * per_slot + 16;
     return true;

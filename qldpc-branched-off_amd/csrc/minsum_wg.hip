@@ -33,6 +33,7 @@ struct WgArgs {
     double *qold;          // DAMP kernels: Q_old per edge, slot-major [round_up(rdeg, 8)][m] per workgroup in HBM/L2 (kernels.py:336-345)
     int qstride;           // doubles per workgroup in qold
     double *vglobal;       // VG kernels: posteriors V[n] per workgroup in HBM/L2 (graphs whose V does not fit next to the check states in LDS)
+    unsigned long long *clk;   // QLDPC_FLAG_CLOCK_PROBE buffer of the launching plan, else NULL
     int *queue;            // next shot to decode (zeroed before the launch): shots are handed out one at a time, so the
                            // workgroups finish together although their shots run 1..max_iter iterations
 };
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     const int m = A.m, n = A.n, max_iter = A.max_iter, tid = threadIdx.x, T = blockDim.x;
     const double clip = A.clip, nclip = -A.clip, damping = A.damping, one_minus_d = 1.0 - A.damping;
     double *Qo = DAMP ? A.qold + (size_t)blockIdx.x * A.qstride : nullptr;
+    const ClkStamp clk0 = clk_begin(A.clk);
     const int deg_own = (tid < m) ? A.indptr[tid + 1] - A.indptr[tid] : 0;                   // the thread's first row, constant over shots
     if (tid == 0) { SP[m] = make_double2(0.0, 0.0); SI[m] = make_uint2(0u, 0u); }            // dummy check read by padded column slots
 
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
         }
         __syncthreads();
     }
+    clk_end(A.clk, clk0);
 }
 
 static size_t wg_lds_bytes(const qldpc_graph *g, bool vg, int &offP, int &offI, int &offF) {
@@ -319,16 +322,16 @@ static size_t wg_lds_bytes(const qldpc_graph *g, bool vg, int &offP, int &offI, 
 }
 
 // 0: not supported, 1: everything in LDS, 2: check states in LDS, posteriors in global memory
-static int wg_mode(const qldpc_graph *g, double damping) {
+static int wg_mode(const qldpc_graph *g, double damping, int flags) {
     (void)damping;                      // damping != 1 keeps Q_old in an HBM/L2 slab
     if (!g->d_ell_col || !g->d_ell_var) return 0;
     if (g->m <= 0 || g->n <= 0 || g->max_row_deg > 56) return 0;
     int a, b, c;
-    if (wg_lds_bytes(g, false, a, b, c) <= 160 * 1024 && !getenv("QLDPC_WG_VGLOBAL")) return 1;
+    if (wg_lds_bytes(g, false, a, b, c) <= 160 * 1024 && !(flags & QLDPC_FLAG_WG_VGLOBAL)) return 1;
     return wg_lds_bytes(g, true, a, b, c) <= 160 * 1024 ? 2 : 0;
 }
 
-bool wg_supported(const qldpc_graph *g, double damping) { return wg_mode(g, damping) != 0; }
+bool wg_supported(const qldpc_graph *g, double damping) { return wg_mode(g, damping, 0) != 0; }
 
 int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
                      double damping, double clip, int flags, bool clean, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
@@ -338,7 +341,7 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     A.indptr = g->d_indptr; A.ell_col = g->d_ell_col; A.ell_var = g->d_ell_var;
     A.B = B; A.synd = d_synd; A.prior = d_prior; A.alpha = d_alpha; A.clip = clip;
     A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;
-    const bool vg = (wg_mode(g, damping) == 2), damp = (damping != 1.0);
+    const bool vg = (wg_mode(g, damping, flags) == 2), damp = (damping != 1.0);
     const size_t lds = wg_lds_bytes(g, vg, A.offP, A.offI, A.offF);
     bool has_deg1 = false;
     for (int i = 0; i < g->m; i++) has_deg1 = has_deg1 || (g->indptr[i + 1] - g->indptr[i] == 1);
@@ -348,6 +351,7 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     if (rcq != QLDPC_OK) return rcq;
     QLDPC_HIP_TRY(hipMemsetAsync(g->ws_queue.p, 0, 16, stream));
     A.queue = g->ws_queue.as<int>();
+    A.clk = g->clk_probe;
     A.vglobal = nullptr; A.qold = nullptr; A.qstride = 0; A.damping = damping;
     if (vg) {
         if ((rcq = g->ws_vals.ensure((size_t)grid * g->n * 8)) != QLDPC_OK) return rcq;
@@ -358,7 +362,7 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
         if ((rcq = g->ws_qold.ensure((size_t)grid * A.qstride * 8)) != QLDPC_OK) return rcq;
         A.qold = g->ws_qold.as<double>();
     }
-    const bool lean = clean && std::isfinite(damping) && !getenv("QLDPC_WG_GENERIC");
+    const bool lean = clean && std::isfinite(damping) && !(flags & QLDPC_FLAG_WG_GENERIC);
     using K = void (*)(WgArgs);
     // [lean][nansel][vg][damp]
     static const K table[2][2][2][2] = {
@@ -368,13 +372,9 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
           {minsum_wg_lean_kernel<false, true, false>, minsum_wg_lean_kernel<false, true, true>}},
          {{minsum_wg_lean_kernel<true, false, false>, minsum_wg_lean_kernel<true, false, true>},
           {minsum_wg_lean_kernel<true, true, false>, minsum_wg_lean_kernel<true, true, true>}}}};
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (int a2 = 0; a2 < 2; a2++) for (int b2 = 0; b2 < 2; b2++) for (int c2 = 0; c2 < 2; c2++) for (int d2 = 0; d2 < 2; d2++)
-            QLDPC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(table[a2][b2][c2][d2]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(table[lean ? 1 : 0][has_deg1 ? 1 : 0][vg ? 1 : 0][damp ? 1 : 0], dim3(grid), dim3(block), lds, stream, A);
+    const K kern = table[lean ? 1 : 0][has_deg1 ? 1 : 0][vg ? 1 : 0][damp ? 1 : 0];
+    if ((rcq = ensure_max_lds(g->device, reinterpret_cast<const void *>(kern), 160 * 1024)) != QLDPC_OK) return rcq;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, A);
     QLDPC_HIP_TRY(hipGetLastError());
     return QLDPC_OK;
 }

@@ -107,8 +107,8 @@ QLDPC_EXPORT int qldpc_noisy_circuit_batch(int64_t B, int64_t len, const int32_t
                                            int64_t n_locs, const double *rv, const int32_t *rp, const int32_t *rt, int64_t cap,
                                            int32_t *out_ops, int32_t *out_q1, int32_t *out_q2, int64_t *out_len) {
     QLDPC_REQUIRE(B >= 0 && len >= 0 && n_locs >= 0 && cap >= 0, "negative size");
-    int rc = use_device(0);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(0);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0) return QLDPC_OK;
     QLDPC_REQUIRE((len == 0 || (ops && q1 && q2)) && (n_locs == 0 || (rv && rp && rt)) && out_len && (cap == 0 || (out_ops && out_q1 && out_q2)),
                   "NULL buffer");
@@ -152,8 +152,8 @@ QLDPC_EXPORT int qldpc_noisy_circuit_batch(int64_t B, int64_t len, const int32_t
 QLDPC_EXPORT int qldpc_frame_sim_batch(int sector_is_x, int64_t B, int64_t cap, const int64_t *len, const int32_t *ops, const int32_t *q1,
                                        const int32_t *q2, int total_qubits, int max_syn, int8_t *hist, int8_t *state, int64_t *counts) {
     QLDPC_REQUIRE(B >= 0 && cap >= 0 && total_qubits >= 0 && max_syn >= 0, "negative size");
-    int rc = use_device(0);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(0);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0) return QLDPC_OK;
     QLDPC_REQUIRE(len && counts && (cap == 0 || (ops && q1 && q2)) && (max_syn == 0 || hist) && (total_qubits == 0 || state), "NULL buffer");
     for (int64_t b = 0; b < B; b++) QLDPC_REQUIRE(len[b] >= 0 && len[b] <= cap, "len[%lld] out of range", (long long)b);
@@ -194,8 +194,8 @@ QLDPC_EXPORT int qldpc_frame_sim_batch(int sector_is_x, int64_t B, int64_t cap, 
 QLDPC_EXPORT int qldpc_sparsify_batch(int64_t B, int64_t stride, const int8_t *hist, const int64_t *syn_count, const int32_t *positions,
                                       const int32_t *ptrs, int num_checks, int8_t *out) {
     QLDPC_REQUIRE(B >= 0 && stride >= 0 && num_checks >= 0, "negative size");
-    int rc = use_device(0);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(0);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0 || stride == 0) return QLDPC_OK;
     QLDPC_REQUIRE(hist && syn_count && out && (num_checks == 0 || (positions && ptrs)), "NULL buffer");
     const int64_t npos = num_checks ? ptrs[num_checks] : 0;

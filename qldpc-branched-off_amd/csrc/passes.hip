@@ -128,8 +128,8 @@ static int check_pass_host(const qldpc_graph *g, int64_t B, const double *Q, con
                            double *Rsum) {
     QLDPC_REQUIRE(g != nullptr, "graph is NULL");
     QLDPC_REQUIRE(B >= 0, "negative batch");
-    int rc = use_device(g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0) return QLDPC_OK;
     QLDPC_REQUIRE(Q && ssign && R && Rsum, "NULL buffer");
     const size_t m = g->m, n = g->n, nnz = g->nnz;
@@ -168,8 +168,8 @@ QLDPC_EXPORT int qldpc_bp_decode_batch(const qldpc_graph *g, int64_t B, const in
                                        int8_t *out_err, double *out_llr, uint8_t *out_conv, int32_t *out_iter) {
     QLDPC_REQUIRE(g != nullptr, "graph is NULL");
     QLDPC_REQUIRE(B >= 0 && max_iter >= 1, "bad batch / max_iter (performBeliefPropagationFast needs max_iter >= 1)");
-    int rc = use_device(g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
+    int rc = QLDPC_OK; (void)rc;
     if (B == 0) return QLDPC_OK;
     QLDPC_REQUIRE(prior && out_err && out_llr && out_conv && out_iter && (syndromes || g->m == 0), "NULL buffer");
     const size_t m = g->m, n = g->n, nnz = g->nnz;
@@ -341,8 +341,8 @@ QLDPC_EXPORT int qldpc_msgstats_create(const qldpc_graph *g, int64_t B, const in
     QLDPC_REQUIRE(B >= 0 && iters >= 0, "negative trial count / iteration count");
     QLDPC_REQUIRE(kind != QLDPC_STATS_POSTERIOR || iters >= 1, "maxIter must be > 0");                      // scopt.py:52-53
     QLDPC_REQUIRE(B == 0 || (errors != nullptr && (prior != nullptr || g->n == 0)), "NULL buffer");
-    int rc = use_device(g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(g->device);
+    int rc = QLDPC_OK; (void)rc;
     *out = nullptr;
     const size_t m = g->m, n = g->n, nnz = g->nnz;
     const bool by_edge = (kind == QLDPC_STATS_CHECK_MESSAGES);
@@ -435,8 +435,8 @@ QLDPC_EXPORT int qldpc_msgstats_histogram(qldpc_msgstats *S, const double *edges
     QLDPC_REQUIRE(S != nullptr && edges != nullptr && hist0 != nullptr && hist1 != nullptr, "NULL argument");
     QLDPC_REQUIRE(bins >= 1 && bins <= kStatsMaxBins, "bins must be in [1, %d]", kStatsMaxBins);
     for (int i = 0; i < bins; i++) QLDPC_REQUIRE(edges[i] < edges[i + 1], "bin edges must increase strictly");
-    int rc = use_device(S->g->device);
-    if (rc != QLDPC_OK) return rc;
+    QLDPC_USE_DEVICE(S->g->device);
+    int rc = QLDPC_OK; (void)rc;
     DevTmp d_edges, d_hist;
     if ((rc = d_edges.alloc((bins + 1) * 8)) || (rc = d_hist.alloc(2 * bins * 8))) return rc;
     QLDPC_HIP_TRY(hipMemcpy(d_edges.p, edges, (bins + 1) * 8, hipMemcpyHostToDevice));

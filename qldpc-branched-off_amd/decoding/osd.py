@@ -7,7 +7,7 @@ from .. import _lib
 from .._lib import check, f64, i8, i32, lib, ptr
 
 
-def performOSD_enhanced(H, syndrome, llr, hard, order=0, max_combinations=None, ordering=None):
+def performOSD_enhanced(H, syndrome, llr, hard, order=0, max_combinations=None, ordering=None, flags=0):
     """Ordered-statistics post-processing -> int64[n] solution.
 
     order == 0: OSD-0 (osd.py:5-29).  order > 0: the reference returns the OSD-0 solution whenever it reproduces the syndrome
@@ -16,7 +16,8 @@ def performOSD_enhanced(H, syndrome, llr, hard, order=0, max_combinations=None, 
     (osd.py:31-75); both branches run on the device.
 
     ``ordering`` (extension) pins the elimination order; default is ascending |llr| with ties by ascending index
-    (the reference's np.argsort default kind leaves the tie order implementation-defined).
+    (the reference's np.argsort default kind leaves the tie order implementation-defined).  ``flags`` (extension, order == 0 only)
+    selects an OSD-0 kernel variant (QLDPC_FLAG_OSD_*; identical results).
     """
     if order < 0:
         order = 0          # the reference's sweep loops are empty for a negative order: it returns the OSD-0 solution
@@ -32,7 +33,7 @@ def performOSD_enhanced(H, syndrome, llr, hard, order=0, max_combinations=None, 
         ordering = i32(ordering).reshape(1, -1)
         op = ptr(ordering, C.c_int32)
     if order == 0:
-        check(lib().qldpc_osd0_batch(g.handle, C.c_int64(1), ptr(s, C.c_int8), ptr(l, C.c_double), ptr(h, C.c_int8), op, ptr(sol, C.c_int8)))
+        check(lib().qldpc_osd0_batch(g.handle, C.c_int64(1), ptr(s, C.c_int8), ptr(l, C.c_double), ptr(h, C.c_int8), op, int(flags), ptr(sol, C.c_int8)))
     else:
         check(lib().qldpc_osdw_batch(g.handle, C.c_int64(1), ptr(s, C.c_int8), ptr(l, C.c_double), ptr(h, C.c_int8), op, C.c_int(int(order)),
                                      C.c_int64(int(max_combinations or 0)), ptr(sol, C.c_int8)))

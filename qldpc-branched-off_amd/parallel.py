@@ -18,21 +18,39 @@ def shard_range(total, rank, world):
     return begin, base + (1 if rank < rem else 0)
 
 
+def local_device(device=None):
+    """The GPU this rank drives: the explicit argument, else LOCAL_RANK (torchrun), else 0."""
+    import os
+    if device is not None:
+        return int(device)
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def collective_device(backend, device=None):
+    """Where the tensors of a collective must live for `backend`: RCCL ("nccl") reduces device tensors only, gloo host tensors.
+    The one rule both helpers below follow."""
+    import torch
+    if backend == "nccl":
+        return torch.device("cuda", local_device(device) if device is not None else torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def allreduce_tally(tally, device=None, group=None):
-    """Sum the int64[16] tally over all ranks (the single collective of the path); identity when not distributed."""
+    """Sum the int64[16] tally over all ranks (the single collective of the path); identity when not distributed.
+    `device`: the rank's GPU index (used when the backend is RCCL; default = torch's current device)."""
     import torch
     import torch.distributed as dist
     t = np.ascontiguousarray(tally, dtype=np.int64)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return t.copy()
-    tt = torch.from_numpy(t.copy())
-    if device is not None:
-        tt = tt.to(device)
+    if isinstance(device, torch.device):
+        device = device.index if device.type == "cuda" else None
+    tt = torch.from_numpy(t.copy()).to(collective_device(dist.get_backend(group), device))
     dist.all_reduce(tt, op=dist.ReduceOp.SUM, group=group)
     return tt.cpu().numpy()
 
 
-def gather_in_shot_order(local, total, group=None):
+def gather_in_shot_order(local, total, group=None, device=None):
     """Concatenate the per-rank uint8 arrays of a `shard_range` split back into global shot order (all ranks get the result)."""
     import torch
     import torch.distributed as dist
@@ -43,7 +61,7 @@ def gather_in_shot_order(local, total, group=None):
     width = -(-int(total) // world)                       # the largest shard; shorter shards are padded
     buf = torch.zeros(max(width, 1), dtype=torch.uint8)
     buf[:local.size] = torch.from_numpy(local.copy())
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    dev = collective_device(dist.get_backend(group), device)
     parts = [torch.empty_like(buf, device=dev) for _ in range(world)]
     dist.all_gather(parts, buf.to(dev), group=group)
     return np.concatenate([parts[r].cpu().numpy()[:shard_range(total, r, world)[1]] for r in range(world)])

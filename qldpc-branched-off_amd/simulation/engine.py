@@ -9,9 +9,11 @@ Differences that are deliberate and documented:
     are reproducible and independent of the number of GPUs, and statistically equivalent to the reference;
   * the alpha / beta estimators (``alpha_mode='alvarado*'``, ``scopt=True``) draw from ``default_rng(base_seed)`` instead of an
     unseeded Generator, so all ranks agree on the factors; their trial loops run on the GPU (qldpc_msgstats_*);
-  * ``osd_order > 0`` behaves exactly like the reference as long as OSD-0 reproduces the syndrome, which it always does for
-    syndromes generated by the circuit itself (the reference then returns the OSD-0 solution too, osd.py:27-29); if a trial ever
-    ends unsatisfied with osd_order > 0, NotImplementedError is raised instead of silently differing;
+  * ``osd_order > 0``: the reference returns the OSD-0 solution whenever it reproduces the syndrome (osd.py:27-29), which it always
+    does for syndromes the circuit itself generates -- those trials stay on the fused device pipeline.  A batch in which some trial
+    ends unsatisfied (possible with foreign ``precomputed_matrices``) is decoded again through the batched OSD-w sweep
+    (qldpc_osdw_batch, osd.py:31-75) for the shots BP failed on, so the result is the reference's for every input;
+  * one process per GPU: ``device`` defaults to LOCAL_RANK; with the RCCL backend the tally all-reduce runs on device tensors;
   * ``target_logical_errors`` stops at the exact trial the reference would (in-order prefix cut over per-trial verdicts).
 """
 import os
@@ -41,9 +43,17 @@ def _estimation_trials(requested, n_cols, error_rate):
 def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, maxIter=50, osd_order=0, use_dynamic_alpha=True,
                    alpha_mode=None, alvarado_alpha=None, alpha_estimation_trials=5000, alpha_estimation_bins=50, precomputed_matrices=None,
                    num_workers=None, base_seed=None, use_jit=True, target_logical_errors=None, max_trials=None, scopt=False,
-                   estimation_plot_dir=None, batch=16384, device=0, **bb_params):
+                   estimation_plot_dir=None, batch=16384, device=None, **bb_params):
     if osd_order < 0:
         raise ValueError("osd_order must be >= 0")
+    device = parallel.local_device(device)        # explicit argument, else LOCAL_RANK of a torchrun launch, else 0
+    try:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized() and _dist.get_backend() == "nccl":
+            import torch
+            torch.cuda.set_device(device)          # RCCL collectives run on the rank's own GPU
+    except ImportError:
+        pass
     if base_seed is None:
         base_seed = int(np.random.randint(0, 2 ** 31))
     if alpha_mode is None:
@@ -108,6 +118,34 @@ def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, m
 
     plan = _lib.CircuitPlan(compiled, Lx, Lz, graphs[0], graphs[1], llrs_z, llrs_x, masks[0], masks[1], error_rate, max_iter=maxIter,
                             alpha_z=alpha_z, alpha_x=alpha_x, alpha_mode=alpha_mode, use_osd=True, batch=batch)
+    T = _lib.TALLY
+
+    def osdw_batch(begin, count):
+        """One trial range through sample -> decode -> OSD-w (order = osd_order) on the shots BP failed on -> logical comparison:
+        (verdicts uint8[count] with bit0 = z_err, bit1 = x_err; tally int64[16]).  The literal per-trial pipeline of the reference
+        (engine.py:68-122) with every stage batched on the device; used only for batches the fused OSD-0 plan left unsatisfied."""
+        spz, tz, spx, tx = plan.sample(base_seed, begin, count)
+        tally = np.zeros(_lib.TALLY_SLOTS, np.int64)
+        verdict = np.zeros(count, np.uint8)
+        tally[T["trials"]] = count
+        for sec, (g, llrs, mask, synd, true, alpha) in enumerate(((graphs[0], llrs_z, masks[0], spz, tz, alpha_z), (graphs[1], llrs_x, masks[1], spx, tx, alpha_x))):
+            det, conv, llr, iters = _lib.minsum_decode_batch(g, synd, llrs, maxIter, alpha_mode, alpha)
+            failed = np.flatnonzero(conv == 0)
+            if failed.size:                                                          # engine.py:96-97 / 115-116
+                det[failed] = _lib.osdw_batch(g, synd[failed], llr[failed], det[failed], osd_order)
+            rows = np.stack([(mask >> np.uint64(r)) & np.uint64(1) for r in range(k)]).astype(np.int64)       # k x n logical rows
+            dec = (det.astype(np.int64) @ rows.T) % 2                                # engine.py:99 / 119
+            err = np.any(dec != true.astype(np.int64), axis=1)                       # engine.py:100 / 120
+            verdict |= (err.astype(np.uint8) << sec)
+            sfx = "zx"[sec]
+            tally[T[sfx + "_err"]] = int(err.sum())
+            tally[T["bp_conv_" + sfx]] = int(conv.sum())
+            tally[T["osd_" + sfx]] = int(failed.size)
+            tally[T["iters_" + sfx]] = int((iters.astype(np.int64) + 1).sum())
+            tally[T["zero_synd_" + sfx]] = int((~synd.any(axis=1)).sum())
+            tally[T["unsat_" + sfx]] = int((_lib.gf2_spmv_batch(g, det) != synd).any(axis=1).sum())
+        tally[T["total_err"]] = int(np.count_nonzero(verdict))
+        return verdict, tally
 
     if max_trials is None:
         max_trials = num_trials if num_trials is not None else 1000000
@@ -119,7 +157,6 @@ def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, m
             rank, world = dist.get_rank(), dist.get_world_size()
     except ImportError:
         pass
-    T = _lib.TALLY
     total = np.zeros(_lib.TALLY_SLOTS, np.int64)
     done = 0
     z_errs = x_errs = total_errs = 0
@@ -136,25 +173,34 @@ def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, m
             # the reference consumes trials in index order and stops AT the trial that brings the count to the target
             # (engine.py:441-464); per-trial verdicts in shot order + a prefix cut reproduce trials_run exactly
             local = plan.run_outcomes(base_seed, done + begin, count) if count else np.zeros(0, np.uint8)
-            verdicts = parallel.gather_in_shot_order(local, this)
+            local_tally = plan.read(clear=True)
+            if osd_order > 0 and count and (local_tally[T["unsat_z"]] or local_tally[T["unsat_x"]]):
+                local, local_tally = osdw_batch(done + begin, count)
+            verdicts = parallel.gather_in_shot_order(local, this, device=device)
             keep = parallel.cut_at_target(verdicts, total_errs, target_logical_errors)
             head = verdicts[:keep]
             z_errs += int(np.count_nonzero(head & 1))
             x_errs += int(np.count_nonzero(head & 2))
             total_errs += int(np.count_nonzero(head))
-            total += parallel.allreduce_tally(plan.read(clear=True))                # diagnostics only: whole rounds
+            total += parallel.allreduce_tally(local_tally, device=device)             # diagnostics only: whole rounds
             done += keep
             if total_errs >= target_logical_errors:
                 break
         else:
-            if count:
-                plan.run(base_seed, done + begin, count)
-            total += parallel.allreduce_tally(plan.read(clear=True))                # engine.py:450-457
+            local_tally = np.zeros(_lib.TALLY_SLOTS, np.int64)
+            for off in range(0, count, batch):                                      # batch by batch: an unsatisfied batch is redone with OSD-w
+                nb = min(batch, count - off)
+                plan.run(base_seed, done + begin + off, nb)
+                if osd_order > 0:
+                    t = plan.read(clear=True)
+                    if t[T["unsat_z"]] or t[T["unsat_x"]]:
+                        t = osdw_batch(done + begin + off, nb)[1]
+                    local_tally += t
+            if osd_order == 0:
+                local_tally = plan.read(clear=True)
+            total += parallel.allreduce_tally(local_tally, device=device)           # engine.py:450-457
             done += this
     plan.close()
-    if osd_order > 0 and (total[T["unsat_z"]] or total[T["unsat_x"]]):
-        raise NotImplementedError("a trial ended with an unsatisfied syndrome: the fused circuit plan runs OSD-0 only (the reference would "
-                                  "enter the OSD-w sweep here, osd.py:31-75; use decoding.osd.performOSD_enhanced for such inputs)")
     if stop_on_errors:
         result = {"logical_error_rate": total_errs / max(1, done), "z_logical_error_rate": z_errs / max(1, done),
                   "x_logical_error_rate": x_errs / max(1, done), "num_trials": done, "logical_errors": total_errs}     # engine.py:466-472

@@ -32,11 +32,27 @@ def test_library_exports_every_declared_symbol(L):
     assert len(decl) >= 20
     for s in decl:
         assert hasattr(lib, s), f"{s} declared in include/qldpc_hip.h but not exported"
-    assert sorted(L.EXPORTS) == decl
+    assert L.exports() == decl                      # the binding is derived from the header: every declaration is bound ...
+    for s in decl:                                  # ... with its full argument list (a mistyped call raises instead of corrupting memory)
+        fn = getattr(lib, s)
+        assert fn.argtypes is not None, s
+        assert len(fn.argtypes) == len(L.signatures()[s][1])
     out = subprocess.run(["nm", "-D", "--defined-only", L.SO_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert set(decl) <= exported
     assert all(e.startswith("qldpc_") for e in exported if not e.startswith("_")), exported
+
+
+def test_mistyped_calls_are_rejected(L):
+    import ctypes as C
+    lib = L.lib()
+    with pytest.raises((C.ArgumentError, TypeError)):
+        lib.qldpc_graph_dims(C.c_void_p(), 1.5, None, None)           # a float where int* is expected
+    with pytest.raises((C.ArgumentError, TypeError)):
+        lib.qldpc_osd0_batch(C.c_void_p(), 0, None, None, None, None, None)   # one argument short (flags)
+    sig = L.signatures()
+    assert sig["qldpc_minsum_decode_batch_dev"][1][2] is C.c_void_p   # device pointers are passed as addresses
+    assert sig["qldpc_minsum_decode_batch"][1][2] == C.POINTER(C.c_int8)
 
 
 def test_version_and_host_helpers(L, oracle):
@@ -177,3 +193,34 @@ def test_circuit_generator_matches_reference_arrays(golden):
             assert np.array_equal(getattr(comp, k), g[k]), (tag, k)
         for k in ("total_qubits", "num_error_locs", "max_circuit_size", "max_syndromes_x", "max_syndromes_z", "num_x_checks", "num_z_checks"):
             assert int(getattr(comp, k)) == int(g[k]), (tag, k)
+
+
+def test_bench_launcher_fails_loudly():
+    """bench.py --gpus N: a WORLD_SIZE that disagrees is an error (it used to run one rank silently), and with WORLD_SIZE unset the parent
+    starts N ranks itself -- on this GPU-less box every rank fails with "no HIP device" and the parent passes the failure on."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present: the self-launch is exercised by the -m gpu suite")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stderr.count("no HIP device") >= 1 and "{" not in r.stdout
+
+
+def test_collective_device_rule():
+    """RCCL reduces device tensors, gloo host tensors: one rule for the tally all-reduce and the verdict gather."""
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd import parallel
+    import torch
+    assert parallel.collective_device("gloo") == torch.device("cpu")
+    assert parallel.collective_device("gloo", 3) == torch.device("cpu")
+    assert parallel.collective_device("nccl", 3) == torch.device("cuda", 3)
+    os.environ["LOCAL_RANK"] = "5"
+    try:
+        assert parallel.local_device() == 5 and parallel.local_device(2) == 2
+    finally:
+        del os.environ["LOCAL_RANK"]
+    assert parallel.local_device() == 0

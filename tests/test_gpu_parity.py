@@ -97,11 +97,9 @@ def test_circuit_level_golden(L, golden, oracle, tag):
         graph = L.Graph(ip, ix, n)
         for fl in (0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM):      # auto = workgroup-per-shot kernel; streaming kernel forced
             check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), fl), g, s)
-        os.environ["QLDPC_WG_GENERIC"] = "1"                          # the generic (any-input) workgroup kernel must agree with the lean one
-        try:
-            check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), 0), g, s)
-        finally:
-            del os.environ["QLDPC_WG_GENERIC"]
+        # the generic (any-input) workgroup kernel and the natural row / column order must agree with the lean, degree-sorted default
+        for fl in (L.FLAG_WG_GENERIC, L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC | L.FLAG_WG_ROWMAJOR):
+            check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), fl), g, s)
         rng = np.random.default_rng(5)                                 # ragged random batch, both kernels, vs the oracle
         synd = (rng.random((37, m)) < 0.1).astype(np.int8)
         ref = oracle.minsum_decode_batch(ip, ix, n, synd, g[f"llrs_{s}"], max_iter=12, threads=0)
@@ -122,14 +120,11 @@ def test_circuit_level_golden(L, golden, oracle, tag):
             assert np.array_equal(sol2, ref2)
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
             # the general global-memory OSD kernel (used when m > 1024) must agree with the LDS-resident one
-            os.environ["QLDPC_OSD_GLOBAL"] = "1"
-            try:
-                sol3 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0)
+            for kfl in (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_LEGACY):           # ... and so must the round-1 Gauss-Jordan LDS kernel
+                sol3 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, flags=kfl)
                 sol4 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0,
-                                           ordering=g[f"{s}_osd_ordering"][t])
-            finally:
-                del os.environ["QLDPC_OSD_GLOBAL"]
-            assert np.array_equal(sol3, ref2) and np.array_equal(sol4, g[f"{s}_osd_solution"][t])
+                                           ordering=g[f"{s}_osd_ordering"][t], flags=kfl)
+                assert np.array_equal(sol3, ref2) and np.array_equal(sol4, g[f"{s}_osd_solution"][t]), (tag, s, t, kfl)
         # OSD-0 on arbitrary (also inconsistent) inputs: random syndromes / llrs with heavy ties / hard decisions
         rng2 = np.random.default_rng(11)
         for trial in range(3):
@@ -443,7 +438,7 @@ def test_api_edge_cases(L, oracle):
     # B = 0 everywhere
     z8 = np.zeros(0, np.int8); zf = np.zeros(0)
     L.check(lib.qldpc_gf2_spmv_batch(g.handle, C.c_int64(0), L.ptr(z8, C.c_int8), L.ptr(z8, C.c_int8)))
-    L.check(lib.qldpc_osd0_batch(g.handle, C.c_int64(0), L.ptr(z8, C.c_int8), L.ptr(zf, C.c_double), L.ptr(z8, C.c_int8), None, L.ptr(z8, C.c_int8)))
+    L.check(lib.qldpc_osd0_batch(g.handle, C.c_int64(0), L.ptr(z8, C.c_int8), L.ptr(zf, C.c_double), L.ptr(z8, C.c_int8), None, 0, L.ptr(z8, C.c_int8)))
     L.check(lib.qldpc_minsum_check_pass(g.handle, C.c_int64(0), L.ptr(zf, C.c_double), L.ptr(zf, C.c_double), C.c_double(1.0), L.ptr(zf, C.c_double), L.ptr(zf, C.c_double)))
     assert np.array_equal(L.cc_sample_decode_tally(g, c["Lx"], 0.01, 1, 0, 0), np.zeros(16, np.int64))
     # max_iter = 0: nothing is decoded; final_iter = -1, not converged (kernels.py:267-268 with an empty loop)
@@ -690,7 +685,7 @@ def test_circuit_level_full_size_properties(L, oracle, golden):
 def test_workgroup_kernel_with_posteriors_in_global_memory(L, oracle, golden, monkeypatch):
     """Graphs whose posteriors do not fit next to the check states in LDS keep V in HBM/L2 (minsum_wg_*<VG = true>).  Forced on the
     golden circuit-level cases (bit-identical LLRs), then on a matrix that really needs it: [[288,12,18]] x 12 cycles (2016 x ~17.5K)."""
-    monkeypatch.setenv("QLDPC_WG_VGLOBAL", "1")
+    VG = L.FLAG_WG_VGLOBAL
     for tag in ("circ72", "circ144"):
         g = golden(tag + "_decode")
         from qldpc_amd.data import load_circuit_matrices
@@ -698,16 +693,15 @@ def test_workgroup_kernel_with_posteriors_in_global_memory(L, oracle, golden, mo
         for s in "ZX":
             n = int(d[f"Hdec{s}_shape"][1])
             graph = L.Graph(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], n)
-            for flags in (0, L.FLAG_FIXED_ITERS):
+            for flags in (VG, VG | L.FLAG_FIXED_ITERS, VG | L.FLAG_WG_ROWMAJOR):
                 err, conv, llr, it = L.minsum_decode_batch(graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), "dynamical", 1.0, flags=flags)
                 assert np.array_equal(err, g[f"{s}_err"]) and np.array_equal(conv.astype(bool), g[f"{s}_conv"].astype(bool))
                 assert np.array_equal(llr, g[f"{s}_llr"]) and np.array_equal(it, g[f"{s}_iter"]), (tag, s, flags)
             # non-clean priors (a -0.0 and an infinity) take the generic kernel
             pr = g[f"llrs_{s}"].copy(); pr[3] = -0.0; pr[7] = np.inf
-            e2, c2, l2, i2 = L.minsum_decode_batch(graph, g[f"{s}_syndromes"][:2], pr, 20, "dynamical", 1.0)
+            e2, c2, l2, i2 = L.minsum_decode_batch(graph, g[f"{s}_syndromes"][:2], pr, 20, "dynamical", 1.0, flags=VG)
             eo, co, lo, io = oracle.minsum_decode_batch(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], n, g[f"{s}_syndromes"][:2], pr, max_iter=20)
             assert np.array_equal(e2, eo) and np.array_equal(l2, lo) and np.array_equal(i2, io)
-    monkeypatch.delenv("QLDPC_WG_VGLOBAL")
     from qldpc_amd.data import load_code
     from qldpc_amd.codes.bb_code import BBCodeCircuit
     from qldpc_amd.noise.builder import build_decoding_matrices
@@ -757,13 +751,8 @@ def test_non_finite_priors_follow_the_reference(L, oracle, golden, monkeypatch):
             for damping, clip, iters in ((1.0, 20.0, 12), (0.75, 9.0, 8)):
                 eo, co, lo, io = oracle.minsum_decode_batch(ip, ix, n, synd, pr, max_iter=iters, damping=damping, clip_llr=clip)
                 for kern in kernels:
-                    if kern == "vg":
-                        monkeypatch.setenv("QLDPC_WG_VGLOBAL", "1")
-                        fl = 0
-                    else:
-                        fl = kern
+                    fl = L.FLAG_WG_VGLOBAL if kern == "vg" else kern
                     e2, c2, l2, i2 = L.minsum_decode_batch(graph, synd, pr, iters, "dynamical", 1.0, damping=damping, clip_llr=clip, flags=fl)
-                    monkeypatch.delenv("QLDPC_WG_VGLOBAL", raising=False)
                     assert np.array_equal(i2, io) and np.array_equal(e2, eo), (tag, variant, damping, kern)
                     assert np.array_equal(np.isnan(l2), np.isnan(lo)) and np.array_equal(l2[~np.isnan(lo)], lo[~np.isnan(lo)]), (tag, variant, damping, kern)
 
@@ -775,7 +764,6 @@ def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch
     import ctypes as C
     from qldpc_amd.decoding.osd import performOSD_enhanced
     from qldpc_amd.data import load_code, load_circuit_matrices
-    monkeypatch.setenv("QLDPC_OSD_UG", "1")
     for tag in ("circ72", "circ144"):
         g = golden(tag + "_decode")
         d = load_circuit_matrices(tag)
@@ -785,9 +773,10 @@ def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch
             from scipy.sparse import csr_matrix
             H = csr_matrix((np.ones(len(ix), np.int8), ix, ip), shape=(len(ip) - 1, n))
             for t, case in enumerate(g[f"{s}_osd_cases"]):
-                sol = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, ordering=g[f"{s}_osd_ordering"][t])
-                assert np.array_equal(sol, g[f"{s}_osd_solution"][t]), (tag, s, t)
-    monkeypatch.delenv("QLDPC_OSD_UG")
+                for kfl in (L.FLAG_OSD_UG, L.FLAG_OSD_UG | L.FLAG_OSD_LEGACY):
+                    sol = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, ordering=g[f"{s}_osd_ordering"][t],
+                                              flags=kfl)
+                    assert np.array_equal(sol, g[f"{s}_osd_solution"][t]), (tag, s, t, kfl)
     from qldpc_amd.codes.bb_code import BBCodeCircuit
     from qldpc_amd.noise.builder import build_decoding_matrices
     c = load_code("bb288")
@@ -806,9 +795,7 @@ def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch
         synd[B - 1] = (rng.random(m) < 0.5)                          # almost surely outside the column space
         llr = rng.normal(4.0, 3.0, (B, n)); llr[1, :50] = 0.0        # ties
         hard = (rng.random((B, n)) < 0.002).astype(np.int8)
-        sol = np.zeros((B, n), np.int8)
-        L.check(L.lib().qldpc_osd0_batch(graph.handle, C.c_int64(B), L.ptr(synd, C.c_int8), L.ptr(llr, C.c_double), L.ptr(hard, C.c_int8), None,
-                                         L.ptr(sol, C.c_int8)))
+        sol = L.osd0_batch(graph, synd, llr, hard)
         for b in range(B):
             want = oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b])
             assert np.array_equal(sol[b], want), (cycles, b, int((sol[b] != want).sum()))
@@ -847,15 +834,14 @@ def test_random_irregular_graphs_all_kernels(L, oracle, monkeypatch):
             clip = float(rng.choice([20.0, 6.5, 50.0]))
             iters = int(rng.integers(1, 25))
             ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=iters, alpha=alpha, alpha_mode=mode, damping=damping, clip_llr=clip)
-            variants = [(0, None), (L.FLAG_FIXED_ITERS, None), (L.FLAG_KERNEL_STREAM, None)]
+            variants = [(0, None), (L.FLAG_FIXED_ITERS, None), (L.FLAG_KERNEL_STREAM, None), (L.FLAG_WG_ROWMAJOR, None)]
             if n >= 2000:
-                variants.append((0, "1"))                              # posteriors in global memory
+                variants.append((L.FLAG_WG_VGLOBAL, "1"))              # posteriors in global memory
+                variants.append((L.FLAG_WG_VGLOBAL | L.FLAG_WG_ROWMAJOR, "1"))
             for flags, vg in variants:
                 if vg:
-                    monkeypatch.setenv("QLDPC_WG_VGLOBAL", vg)
                     ran["vg"] += 1
                 out = L.minsum_decode_batch(graph, synd, prior, iters, mode, alpha, damping=damping, clip_llr=clip, flags=flags)
-                monkeypatch.delenv("QLDPC_WG_VGLOBAL", raising=False)
                 ran["stream"] += flags == L.FLAG_KERNEL_STREAM
                 for name, a, b in zip(("err", "conv", "llr", "iter"), (out[0], out[1].astype(bool), out[2], out[3]), (ref[0], ref[1].astype(bool), ref[2], ref[3])):
                     assert np.array_equal(a, b, equal_nan=True), (gi, trial, flags, vg, name, mode, damping, clip, iters)
@@ -883,14 +869,8 @@ def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
         llr = rng.normal(1.0, 3.0, (B, n)); llr[0, : n // 3] = 1.25; llr[1] = np.round(llr[1])     # ties
         hard = (rng.random((B, n)) < 0.1).astype(np.int8)
         want = np.stack([oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)])
-        for env in (None, "QLDPC_OSD_UG", "QLDPC_OSD_GLOBAL"):
-            if env:
-                monkeypatch.setenv(env, "1")
-            sol = np.zeros((B, n), np.int8)
-            L.check(L.lib().qldpc_osd0_batch(graph.handle, C.c_int64(B), L.ptr(synd, C.c_int8), L.ptr(llr, C.c_double), L.ptr(hard, C.c_int8), None,
-                                             L.ptr(sol, C.c_int8)))
-            if env:
-                monkeypatch.delenv(env)
+        for env in (0, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_LEGACY, L.FLAG_OSD_LEGACY | L.FLAG_OSD_UG, L.FLAG_OSD_NOKILL):
+            sol = L.osd0_batch(graph, synd, llr, hard, flags=env)
             assert np.array_equal(sol, want), (gi, env, np.flatnonzero((sol != want).any(1)))
 
 
@@ -1052,7 +1032,7 @@ def test_device_resident_decode_osd_check_chain(L, oracle):
         sel = torch.nonzero(dc == 0).flatten().to(torch.int32)          # stays on the device
         cnt = torch.tensor([sel.numel()], dtype=torch.int32, device="cuda")
         dsol = de.clone()                                               # converged shots keep the BP decision
-        L.check(L.lib().qldpc_osd0_batch_dev(g.handle, C.c_int64(B), p(ds), p(dl), p(de), None, p(sel), p(cnt), p(dsol), s))
+        L.check(L.lib().qldpc_osd0_batch_dev(g.handle, C.c_int64(B), p(ds), p(dl), p(de), None, p(sel), p(cnt), 0, p(dsol), s))
         L.check(L.lib().qldpc_gf2_spmv_batch_dev(g.handle, C.c_int64(B), p(dsol), p(dchk), s))
         st.synchronize()
     assert np.array_equal(dsol.cpu().numpy(), want)
@@ -1060,7 +1040,109 @@ def test_device_resident_decode_osd_check_chain(L, oracle):
     # without a selection every shot is solved
     with torch.cuda.stream(st):
         dall = torch.empty_like(de)
-        L.check(L.lib().qldpc_osd0_batch_dev(g.handle, C.c_int64(B), p(ds), p(dl), p(de), None, None, None, p(dall), s))
+        L.check(L.lib().qldpc_osd0_batch_dev(g.handle, C.c_int64(B), p(ds), p(dl), p(de), None, None, None, 0, p(dall), s))
         st.synchronize()
     b = int(np.flatnonzero(conv_o == 1)[0])
     assert np.array_equal(dall.cpu().numpy()[b], oracle.osd0(ip, ix, n, synd[b], llr_o[b], err_o[b]))
+
+
+def test_bench_starts_its_own_ranks(L, tmp_path):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts two ranks by itself (gloo here: both share this box's one card; on an
+    8-GPU node the same command line runs over RCCL).  The line it prints must account for both ranks' shots and trials."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["QLDPC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "65536",
+                        "--circuit", "circ72", "--circuit-batch", "1024", "--circuit-steps", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout                                   # exactly one JSON line: rank 0's
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 2
+    assert out["tally"]["trials"] == 2 * 2 * 65536                    # world x steps x batch shots went through the all-reduce
+    assert out["circuit_level"]["tally"]["trials"] == 2 * 2 * 1024
+    assert out["value"] > 0 and out["circuit_level"]["value"] > 0
+    # the same shots on one rank give the same tally (the Philox streams are keyed by the global shot index)
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "65536",
+                         "--circuit", "circ72", "--circuit-batch", "1024", "--circuit-steps", "4", "--no-cpu-baseline"],
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert one["tally"] == out["tally"] and one["circuit_level"]["tally"] == out["circuit_level"]["tally"]
+    assert set(one["circuit_level"]["phases_ms_per_step"]) == set(L.CIRCUIT_PHASES)
+    assert one["roofline"]["clock_mhz"] is None or 500 < one["roofline"]["clock_mhz"] < 3000
+
+
+def test_native_rccl_tally_allreduce(L):
+    """(e) natively on RCCL through the C ABI (no torch): a world of one is the identity, through both ways of forming the communicator.
+    N > 1 needs an N-GPU node and stays unmeasured here."""
+    t = np.arange(16, dtype=np.int64) * 1000003 + 7
+    comm = L.Comm.init_all(1)
+    assert (comm.nranks, comm.nlocal) == (1, 1)
+    assert np.array_equal(comm.allreduce(t), t)
+    assert np.array_equal(comm.allreduce(t.reshape(1, 16)), t.reshape(1, 16))
+    comm.close()
+    uid = L.Comm.unique_id()
+    assert len(uid) == 128
+    c2 = L.Comm.init_rank(1, 0, uid, 0)
+    assert np.array_equal(c2.allreduce(t), t)
+    c2.close()
+    with pytest.raises(L.QldpcError):
+        L.Comm.init_all(L.device_count() + 1)
+
+
+def test_run_simulation_osd_order_on_unsatisfiable_trials(L, oracle):
+    """run_simulation(osd_order = 2) with FOREIGN decoding matrices (most columns removed, so the circuit's syndromes fall outside the
+    column space): OSD-0 leaves those trials unsatisfied and the reference enters the combination sweep (osd.py:31-75).  The engine
+    routes such batches through qldpc_osdw_batch; verdicts equal the per-trial pipeline assembled from the oracle's pieces."""
+    import scipy.sparse as sp
+    from qldpc_amd.data import load_code, load_precomputed_matrices
+    from qldpc_amd.simulation.engine import run_simulation, prior_llrs
+    from qldpc_amd.codes.bb_code import BBCodeCircuit
+    from qldpc_amd.noise.compiled import CompiledCircuit
+    c = load_code("bb72")
+    bb = dict(ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+    M = load_precomputed_matrices("circ72")
+    rng = np.random.default_rng(17)
+    F, secs = {"num_cycles": 6, "k": M["k"]}, []
+    for s in "ZX":
+        H = M[f"Hdec{s}"].tocsc()
+        n = H.shape[1]
+        keep = np.sort(rng.choice(n, 160, replace=False))
+        lip, lix = M[f"H{s}_logical"]
+        Ld = sp.csr_matrix((np.ones(len(lix), np.int8), lix, lip), shape=(len(lip) - 1, n)).toarray()[:, keep]
+        F[f"Hdec{s}"] = sp.csr_matrix(H[:, keep])
+        F[f"H{s}_logical"] = Ld
+        F[f"channel_probs{s}"] = M[f"channel_probs{s}"][keep]
+        ip, ix, _ = L.canonical_csr(F[f"Hdec{s}"])
+        secs.append((ip, ix, len(keep), prior_llrs(F[f"channel_probs{s}"]), Ld))
+    N, seed, p = 96, 4321, 0.005
+    res = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], p, num_trials=N, num_cycles=6, maxIter=20, osd_order=2, precomputed_matrices=F,
+                         base_seed=seed, batch=32, **bb)
+    cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=6, **bb)
+    comp = CompiledCircuit(cb.get_full_circuit(), cb.cycle * 2, cb.lin_order, cb.data_qubits, cb.Xchecks, cb.Zchecks)
+    circ = oracle.make_circuit(comp, c["Lx"], c["Lz"])
+    z_err = x_err = tot = unsat = 0
+    for t in range(N):
+        spz, tz, spx, tx = oracle.circuit_sample(circ, p, seed, t)
+        bad = []
+        for (ip, ix, n, prior, Ld), synd, true in zip(secs, (spz, spx), (tz, tx)):
+            err, conv, llr, it = oracle.minsum_decode_batch(ip, ix, n, synd[None, :], prior, max_iter=20)
+            det = err[0]
+            if not conv[0]:
+                det = oracle.osdw(ip, ix, n, synd, llr[0], err[0], 2)
+                unsat += int(not np.array_equal(oracle.syndrome_check(ip, ix, det.astype(np.int8)), synd))
+            bad.append(bool(np.any((Ld.astype(np.int64) @ det.astype(np.int64)) % 2 != true)))
+        z_err += bad[0]; x_err += bad[1]; tot += bad[0] or bad[1]
+    assert unsat > 10                                                  # the sweep really ran on unsatisfiable syndromes
+    T = L.TALLY
+    assert (res["num_trials"], res["logical_errors"]) == (N, tot)
+    assert (int(res["tally"][T["z_err"]]), int(res["tally"][T["x_err"]])) == (z_err, x_err)
+    # target_logical_errors goes through the same routing: the exact stop trial of the in-order loop
+    stop = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], p, num_trials=N, num_cycles=6, maxIter=20, osd_order=2, precomputed_matrices=F,
+                          base_seed=seed, batch=32, target_logical_errors=5, **bb)
+    assert stop["logical_errors"] == 5 and stop["num_trials"] <= N

@@ -21,6 +21,8 @@ ap.add_argument("--batch", type=int, default=16384)
 ap.add_argument("--max-iter", type=int, default=50)
 ap.add_argument("--no-osd", action="store_true")
 ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
+ap.add_argument("--serial", action="store_true", help="both sectors on one stream (QLDPC_FLAG_MC_UNFUSED): per-phase times are then exclusive")
+ap.add_argument("--reps", type=int, default=1)
 ap.add_argument("--cpu-trials", type=int, default=0, help="also time the CPU checker (C port of the reference loop, all host threads) on this many trials")
 a = ap.parse_args()
 d = load_circuit_matrices(a.tag)
@@ -35,6 +37,8 @@ for s in "ZX":
     pr.append(prior_llrs(d[f"channel_probs{s}"]))
     mk.append(_lib.logical_column_masks((d[f"H{s}_logical_indptr"], d[f"H{s}_logical_indices"]), n))
 t0 = time.perf_counter()
+if a.serial:
+    a.flags |= _lib.FLAG_MC_UNFUSED
 plan = _lib.CircuitPlan(comp, c["Lx"], c["Lz"], gr[0], gr[1], pr[0], pr[1], mk[0], mk[1], 0.005, max_iter=a.max_iter, use_osd=not a.no_osd,
                         flags=a.flags, batch=a.batch)
 print(f"plan create (signature tables): {time.perf_counter() - t0:.2f}s", flush=True)
@@ -43,20 +47,35 @@ t0 = time.perf_counter()
 spz, tz, spx, tx = plan.sample(5, 0, min(a.trials, 4096))
 dt = time.perf_counter() - t0
 print(f"sampler alone (incl. D2H): {min(a.trials, 4096) / dt:.0f} trials/s; mean syndrome weight Z {spz.sum(1).mean():.1f} X {spx.sum(1).mean():.1f}", flush=True)
-t0 = time.perf_counter()
-plan.run(5, 0, a.trials)
-t = plan.read()
-dt = time.perf_counter() - t0
 T = _lib.TALLY
-print(f"{a.tag} max_iter={a.max_iter} osd={not a.no_osd}: {a.trials / dt:.1f} trials/s ({dt:.2f}s); LER={t[T['total_err']] / t[0]:.3f} "
-      f"conv_z={t[T['bp_conv_z']] / t[0]:.2f} conv_x={t[T['bp_conv_x']] / t[0]:.2f} osd={t[T['osd_z']]}+{t[T['osd_x']]} "
-      f"mean_it_z={t[T['iters_z']] / t[0]:.1f} unsat={t[T['unsat_z']]}+{t[T['unsat_x']]}", flush=True)
+for rep in range(a.reps):
+    plan.read(clear=True); plan.phase_times()
+    try:
+        _lib.osd_timers(reset=True)
+        timers = True
+    except _lib.QldpcError:
+        timers = False
+    t0 = time.perf_counter()
+    plan.run(5, 0, a.trials)
+    t = plan.read()
+    dt = time.perf_counter() - t0
+    ph, nb = plan.phase_times()
+    print(f"{a.tag} max_iter={a.max_iter} osd={not a.no_osd} flags={a.flags:#x}: {a.trials / dt:.1f} trials/s ({dt:.2f}s); LER={t[T['total_err']] / t[0]:.3f} "
+          f"conv_z={t[T['bp_conv_z']] / t[0]:.2f} conv_x={t[T['bp_conv_x']] / t[0]:.2f} osd={t[T['osd_z']]}+{t[T['osd_x']]} "
+          f"mean_it_z={t[T['iters_z']] / t[0]:.1f} unsat={t[T['unsat_z']]}+{t[T['unsat_x']]}", flush=True)
+    print("  phases ms/batch: " + " ".join(f"{k}={v / max(nb, 1):.2f}" for k, v in ph.items()) + f"  tally={t[:14].tolist()}", flush=True)
+    if a.flags & _lib.FLAG_CLOCK_PROBE:
+        print("  clock MHz (bp, osd):", plan.clock(), flush=True)
+    if timers:
+        h = _lib.osd_timers(reset=True).astype(float)
+        if h[0]:
+            print(f"  [osd timers] shots={h[0]:.0f} chunks/shot={h[1] / h[0]:.2f} cols/shot={h[2] / h[0]:.1f} pivots/shot={h[3] / h[0]:.1f} kills/shot={h[5] / h[0]:.1f} "
+                  f"blocks/shot={h[6] / h[0]:.1f} kcycles/shot={h[4] / h[0] / 1e3:.1f} (sort {h[8] / h[0] / 1e3:.0f} p1 {h[9] / h[0] / 1e3:.0f} p2 {h[10] / h[0] / 1e3:.0f} "
+                  f"p3 {h[11] / h[0] / 1e3:.0f} kill {h[12] / h[0] / 1e3:.0f} backsub {h[13] / h[0] / 1e3:.0f})", flush=True)
 
 if a.cpu_trials > 0:
     from oracle import oracle as orc            # CPU checker, timed beside the GPU path (never part of it)
-    with np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", a.tag + "_noise.npz")) as z:
-        g = {k: z[k] for k in z.files}          # the circuit arrays in the form the checker takes
-    circ = orc.make_circuit(g, g["Lx"], g["Lz"])
+    circ = orc.make_circuit(comp, c["Lx"], c["Lz"])
     secs = [orc.make_sector(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], int(d[f"Hdec{s}_shape"][1]), orc.prior_llrs(d[f"channel_probs{s}"]),
                             d[f"H{s}_logical_indptr"], d[f"H{s}_logical_indices"]) for s in "ZX"]
     t0 = time.perf_counter()

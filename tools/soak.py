@@ -152,15 +152,15 @@ while time.time() < t_end:
         flags = int(rng.choice([0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM, L.FLAG_KERNEL_GENERIC if n < 1000 else 0]))
         env = rng.random() < 0.2 and n > 1000
         if env:
-            os.environ["QLDPC_WG_VGLOBAL"] = "1"
+            flags |= L.FLAG_WG_VGLOBAL
+        if n > 1000 and rng.random() < 0.3:
+            flags |= int(rng.choice([L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC]))
         try:
             out = L.minsum_decode_batch(g, synd, prior, iters, mode, alpha, damping=damping, clip_llr=clip, flags=flags)
         except L.QldpcError as e:
             if "does not support" in str(e):
                 continue
             raise
-        finally:
-            os.environ.pop("QLDPC_WG_VGLOBAL", None)
         ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=iters, alpha=alpha, alpha_mode=mode, damping=damping, clip_llr=clip)
         for nm, x, y in zip(("err", "conv", "llr", "iter"), (out[0], out[1].astype(bool), out[2], out[3]), (ref[0], ref[1].astype(bool), ref[2], ref[3])):
             if not np.array_equal(x, y, equal_nan=True):
@@ -191,13 +191,9 @@ while time.time() < t_end:
         if rng.random() < 0.5:
             llr = np.round(llr)
         hard = (rng.random((B, n)) < 0.01).astype(np.int8)
-        env = str(rng.choice(["", "QLDPC_OSD_UG", "QLDPC_OSD_GLOBAL"])) if tag == "circ72" else str(rng.choice(["", "QLDPC_OSD_UG"]))
-        if env:
-            os.environ[env] = "1"
-        sol = np.zeros((B, n), np.int8)
-        L.check(L.lib().qldpc_osd0_batch(g.handle, C.c_int64(B), L.ptr(synd, C.c_int8), L.ptr(llr, C.c_double), L.ptr(hard, C.c_int8), None, L.ptr(sol, C.c_int8)))
-        if env:
-            os.environ.pop(env)
+        variants = [0, 0, L.FLAG_OSD_UG, L.FLAG_OSD_LEGACY, L.FLAG_OSD_LEGACY | L.FLAG_OSD_UG, L.FLAG_OSD_NOKILL] + ([L.FLAG_OSD_GLOBAL] if tag == "circ72" else [])
+        env = int(rng.choice(variants))
+        sol = L.osd0_batch(g, synd, llr, hard, flags=env)
         for b in range(B):
             if not np.array_equal(sol[b], oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b])):
                 fail(f"osd {tag}{s} env={env} b={b} seed={a.seed} n={count}")
