@@ -678,11 +678,6 @@ constexpr int kOsdBlock = QLDPC_OSD_BLOCK;      // columns resolved per block (4
 static_assert(kOsdBlock <= 16, "one wave per column, at most 4 columns per wave with 256-thread blocks");
 __device__ __forceinline__ unsigned long long r_mask_word(const unsigned long long *R, int t, int mw, int w) { return R[t * mw + w]; }
 
-__device__ __forceinline__ unsigned long long osd_key(double x) {
-    double a = fabs(x);
-    if (a != a) a = INFINITY;
-    return (unsigned long long)__double_as_longlong(a);          // non-negative doubles order like their bit patterns
-}
 // U is stored row-major with an XOR swizzle of the word index when rows are 16 words (128 B): conflict-free row-parallel updates
 __device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ (q & 15)) : w); }
 
@@ -725,16 +720,9 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         const long long t_start = OSD_CLOCK();
         // ---- column order: ascending |llr| (osd.py:11-12), ties by ascending index; bitonic sort of (key, index) in LDS ----
         if (!P.ordering) {
-            // Stable LSD radix sort of the column indices by the 64-bit key, 8 passes of 8 bits (a bitonic network of (key, index)
-            // pairs cost 0.44 M cycles per shot, all of it compare-exchange instructions).  The keys stay where they are; a pass
-            // permutes the index array only.  Stability -- which is what makes ties come out in ascending index order, the
-            // permutation starting as the identity -- comes from (a) every wave owning a contiguous range of positions and walking it
-            // in order, (b) a lane's rank among the lanes of its step with the same digit (8 ballots), (c) an exclusive scan of the
-            // [digit][wave] counters in digit-major order.
             unsigned long long *keys;                                                               // [n]   (LDS: aliases U)
             uint16_t *pa, *pb;                                                                      // [n] each
-            unsigned *cnt;                                                                          // [256][NW] + [NW]
-            const int NW = T >> 6, wv = tid >> 6, lane = tid & 63;
+            unsigned *cnt;                                                                          // [256][waves] + [waves]
             if (UG) {
                 keys = P.ugkeys + (size_t)blockIdx.x * (size_t)(n + (n + 1) / 2);
                 pa = reinterpret_cast<uint16_t *>(keys + n); pb = pa + n;
@@ -744,100 +732,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 pa = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8); pb = pa + n;
                 cnt = reinterpret_cast<unsigned *>(lds + (((size_t)n * 12 + 15) & ~(size_t)15));
             }
-            unsigned *wsum = cnt + 256 * NW;
-            const int span = (((n + NW - 1) / NW) + 63) & ~63;                                      // positions per wave, a multiple of 64
-            const int wbeg = wv * span, wend = min(n, wbeg + span);
-            for (int j = tid; j < n; j += T) { keys[j] = osd_key(llr[j]); pa[j] = (uint16_t)j; }
-            for (int pass = 0; pass < 8; pass++) {
-                const int shift = 8 * pass;
-                for (int e = tid; e < 256 * NW; e += T) cnt[e] = 0u;
-                __syncthreads();
-                constexpr int kSteps = 10;                                                          // steps of 64 positions kept in registers
-                const bool cached = (span <= 64 * kSteps);
-                int cj[kSteps];
-                unsigned cd[kSteps];
-                unsigned long long csame[kSteps];
-                if (cached) {                                                                       // all index / key loads of the pass in flight at once
-#pragma unroll
-                    for (int st = 0; st < kSteps; st++) { const int pos = wbeg + 64 * st + lane; cj[st] = (pos < wend) ? (int)pa[pos] : 0; }
-#pragma unroll
-                    for (int st = 0; st < kSteps; st++) {
-                        const int pos = wbeg + 64 * st + lane;
-                        cd[st] = (pos < wend) ? (unsigned)((keys[cj[st]] >> shift) & 255ull) : 0u;
-                    }
-#pragma unroll
-                    for (int st = 0; st < kSteps; st++) {
-                        const bool valid = (wbeg + 64 * st + lane) < wend;
-                        unsigned long long same = __ballot(valid);                                  // lanes of this step holding the same digit
-#pragma unroll
-                        for (int b2 = 0; b2 < 8; b2++) {
-                            const unsigned long long bal = __ballot((cd[st] >> b2) & 1u);
-                            same &= ((cd[st] >> b2) & 1u) ? bal : ~bal;
-                        }
-                        csame[st] = valid ? same : 0ull;
-                    }
-                }
-                for (int round = 0; round < 2; round++) {                                           // 0: count, 1: scatter
-                    if (cached) {
-#pragma unroll
-                        for (int st = 0; st < kSteps; st++) {
-                            if (csame[st] != 0ull) {
-                                const int rank = __builtin_popcountll(csame[st] & ((1ull << lane) - 1ull)), tot = __builtin_popcountll(csame[st]);
-                                unsigned *slot = cnt + cd[st] * NW + wv;
-                                if (round == 0) {
-                                    if (rank == 0) *slot += (unsigned)tot;                          // one leader per digit; the column [.][wv] is this wave's own
-                                } else {
-                                    const unsigned base = *slot;                                    // read by the whole group before its leader advances it
-                                    pb[base + rank] = (uint16_t)cj[st];
-                                    if (rank == 0) *slot = base + (unsigned)tot;
-                                }
-                            }
-                        }
-                    } else
-                    for (int p0 = wbeg; p0 < wend; p0 += 64) {
-                        const int pos = p0 + lane;
-                        const bool valid = pos < wend;
-                        const int j = valid ? (int)pa[pos] : 0;
-                        const unsigned d = valid ? (unsigned)((keys[j] >> shift) & 255ull) : 0u;
-                        unsigned long long same = __ballot(valid);
-#pragma unroll
-                        for (int b2 = 0; b2 < 8; b2++) {
-                            const unsigned long long bal = __ballot((d >> b2) & 1u);
-                            same &= ((d >> b2) & 1u) ? bal : ~bal;
-                        }
-                        if (valid) {
-                            const int rank = __builtin_popcountll(same & ((1ull << lane) - 1ull)), tot = __builtin_popcountll(same);
-                            unsigned *slot = cnt + d * NW + wv;
-                            if (round == 0) {
-                                if (rank == 0) *slot += (unsigned)tot;
-                            } else {
-                                const unsigned base = *slot;
-                                pb[base + rank] = (uint16_t)j;
-                                if (rank == 0) *slot = base + (unsigned)tot;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    if (round == 0) {                                                               // exclusive scan over (digit, wave), 4 entries per thread
-                        unsigned v[4], sum = 0u;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) { v[e] = cnt[4 * tid + e]; sum += v[e]; }
-                        unsigned inc = sum;
-#pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o); if (lane >= o) inc += up; }
-                        if (lane == 63) wsum[wv] = inc;
-                        __syncthreads();
-                        unsigned before = inc - sum;
-                        for (int w2 = 0; w2 < wv; w2++) before += wsum[w2];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) { cnt[4 * tid + e] = before; before += v[e]; }
-                        __syncthreads();
-                    }
-                }
-                uint16_t *tsw = pa; pa = pb; pb = tsw;
-            }
-            for (int j = tid; j < n; j += T) ordw[j] = pa[j];
-            __syncthreads();
+            osd_radix_sort(llr, n, keys, pa, pb, cnt, ordw);
         }
         // ---- init: T = I (positions = original rows), b = s + H hard (osd.py:8-9) ----
         for (int t = tid; t < (m + 2) * mw; t += T) U[t] = 0ull;
@@ -1069,8 +964,11 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     clk_end(P.clk, clk0);
 }
 
+int osd0_fwd_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
+
 // rank of H over GF(2) (host, once per graph): the sweep above can stop as soon as this many pivots exist
-static int host_rank(const qldpc_graph *g) {
+int host_gf2_rank(const qldpc_graph *g) {
     const int m = g->m, n = g->n, nw = (n + 63) / 64;
     std::vector<uint64_t> A((size_t)m * nw, 0);
     for (int i = 0; i < m; i++)
@@ -1119,9 +1017,13 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     OsdLdsArgs P;
     size_t lds = 0;
     handled = false;
+    if (!(flags & (QLDPC_FLAG_OSD_LEGACY | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // default: the forward-elimination kernel (m <= 1024)
+        const int rcf = osd0_fwd_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
+        if (rcf != QLDPC_OK || handled) return rcf;
+    }
     const int mode = (flags & QLDPC_FLAG_OSD_GLOBAL) ? 0 : plan_osd_lds(g, P, lds, flags);
     if (mode == 0) return QLDPC_OK;
-    if (g->gf2_rank < 0) g->gf2_rank = host_rank(g);      // callers hold g->mu
+    if (g->gf2_rank < 0) g->gf2_rank = host_gf2_rank(g);      // callers hold g->mu
     P.rankH = g->gf2_rank;
     const int grid = 512;
     const size_t sz_ord = (size_t)round_up((int64_t)grid * g->n * 2 + 64, 16);

@@ -215,6 +215,7 @@ QLDPC_EXPORT void qldpc_graph_destroy(qldpc_graph *g) {
         if (p) (void)hipFree(p);
     if (g->d_ell_col) (void)hipFree(g->d_ell_col);
     if (g->d_ell_var) (void)hipFree(g->d_ell_var);
+    if (g->d_col_rows) (void)hipFree(g->d_col_rows);
     g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_list.release();
     for (auto &e : g->alpha_cache) { if (e.dev) (void)hipFree(e.dev); if (e.pinned) (void)hipHostFree(e.pinned); if (e.ready) (void)hipEventDestroy(e.ready); }
     if (g->ws_event) (void)hipEventDestroy(g->ws_event);
