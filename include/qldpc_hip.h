@@ -60,7 +60,8 @@ extern "C" {
 #define QLDPC_FLAG_OSD_UG 0x400         /* OSD-0: row transform in HBM/L2 even when it fits LDS (the m > 1024 form) */
 #define QLDPC_FLAG_OSD_GLOBAL 0x800     /* OSD-0: the literal global-memory elimination (general fallback) */
 #define QLDPC_FLAG_OSD_NOKILL 0x1000    /* OSD-0: no parallel dependent-column tests */
-#define QLDPC_FLAG_OSD_LEGACY 0x2000    /* OSD-0: the round-1 Gauss-Jordan LDS kernel instead of the forward-elimination kernel */
+#define QLDPC_FLAG_OSD_FWD 0x2000       /* OSD-0: the forward-elimination + back-substitution kernel (m <= 1024; measured slower than the default
+                                           Gauss-Jordan LDS kernel on the circuit-level matrices, kept as a checked alternative) */
 #define QLDPC_FLAG_CLOCK_PROBE 0x4000   /* plans: workgroups stamp s_memtime / s_memrealtime around their work (see *_plan_clock) */
 #define QLDPC_FLAG_WG_ROWMAJOR 0x8000   /* workgroup-per-shot decoder: natural row / column order instead of the degree-sorted assignment */
 

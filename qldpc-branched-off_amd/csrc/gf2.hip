@@ -1017,7 +1017,7 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     OsdLdsArgs P;
     size_t lds = 0;
     handled = false;
-    if (!(flags & (QLDPC_FLAG_OSD_LEGACY | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // default: the forward-elimination kernel (m <= 1024)
+    if ((flags & QLDPC_FLAG_OSD_FWD) && !(flags & (QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // the forward-elimination kernel (m <= 1024)
         const int rcf = osd0_fwd_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
         if (rcf != QLDPC_OK || handled) return rcf;
     }

@@ -23,8 +23,15 @@
 //   * the solution: for the pivots t = r-1 .. 0, e_t = b'[t], and if e_t the column's reduced form above the diagonal is added to b'.
 //     Those upper parts are recomputed from the final U (row t of T is frozen once t has pivoted), 64 columns at a time, and
 //     consumed by one wave.
-// Results are identical to the reference's on every input (also for syndromes outside the column space); tests compare solutions
-// against the oracle's literal Gauss-Jordan and against the reference's own outputs.
+// Results are identical to the reference's on every input (also for syndromes outside the column space); the tests compare solutions
+// with a literal Gauss-Jordan on the CPU and with the reference's own outputs.
+//
+// STATUS (round 2, measured on 1 x MI355X, profiles/r02_osd_fwd_experiment.txt): correct, but NOT faster than the round-1 Gauss-Jordan
+// kernel on the circuit-level matrices (4.3 M vs 3.5 M cycles per shot), so it is selected only by QLDPC_FLAG_OSD_FWD.  Phase 3 here is
+// cheaper (1.0 M vs 1.29 M cycles per shot) but phase 2 is not: a lone wave issues one instruction per four cycles and every
+// VALU -> SALU -> VALU hop of the pivot chain costs more, 1.4 k cycles per pivot in every formulation tried (all 16 words per step; only
+// the two words next to the pivot row with the rest caught up in parallel -- useless here: the reduced columns of these matrices are
+// sparse, 60 of 70 blocks per shot have a pivot further away).  The round-1 kernel pays 1.2 k per pivot with four waves and a barrier.
 #include "common.h"
 #include "mc_common.h"
 #include "osd_common.h"
@@ -50,11 +57,20 @@ struct OsdFwdArgs {
     int offIdx, offAlive, offRows, offPc, offR, offRL, offBlk;
 };
 
+#define LDSP __attribute__((address_space(3)))
 typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
 // U is stored row-major with an XOR swizzle of the word index when rows are 16 words (128 B): conflict-free row-parallel access
 __device__ __forceinline__ int fswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ (q & 15)) : w); }
+
+// wave-uniform values that arrive as arguments of a non-inlined function live in vector registers: hand them back to the scalar unit
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
 
 // 64 bytes from a wave-uniform global address into scalar registers (the masks of phase 3: no LDS, no VGPRs, free broadcast)
 // (load and wait are one statement: between a bare s_load and its s_waitcnt the compiler could copy the not-yet-written registers)
@@ -82,7 +98,7 @@ __device__ __forceinline__ void sprefetch_block(const uint32_t *p) {
 // dead.  maskg holds A_k = mask ^ E_pp (mask itself when a == pp); lane k of ppv holds pp_k.  The row is a 32-dword vector indexed through s_set_gpr_idx; the
 // one dynamic write per operation is unconditional (a uniform branch around it makes the compiler copy all 32 registers).
 template <int W0>
-__device__ __forceinline__ void fwd_apply_row(unsigned long long *U, int q, int mw, int row0, int nops, int ppv, const uint32_t *maskg) {
+__device__ __forceinline__ void fwd_apply_row(LDSP unsigned long long *U, int q, int mw, int row0, int nops, int ppv, const uint32_t *maskg) {
     u32x32 u;
 #pragma unroll
     for (int d = 0; d < 32; d++) u[d] = 0u;
@@ -136,83 +152,97 @@ __device__ __forceinline__ void fwd_apply_row(unsigned long long *U, int q, int 
 // 64 (WQ0 + i) + l; words left of the block's first pivot are final and never loaded).  Column t pivots at the first position >= lrow
 // holding a one (kernels.py:71-75); the rows at positions lrow and pp swap (kernels.py:79-82) in column t and the later columns; the
 // pivot row is added to every row BELOW it that has a one in column t (kernels.py:88-92, forward part), later columns only.
-// A lone wave is latency bound (every instruction waits for the previous one), so the step is written for instruction count: the
-// pivot of a reduced column sits in the first or second live word with probability 1 - 2^-64 once the transform has filled in, and
-// that case is straight-line code; pivots further away (the first blocks of a shot, when T is still near the identity) take the
-// generic loop.
+// A lone wave issues one instruction per four cycles whatever it is, so the serial chain is kept to the TWO words the block's pivots
+// live in (positions lrow .. lrow + 15 and, once the transform has filled in, the pivot a few positions behind lrow): per step two
+// ballots, two lane reads, branch-free selects on those two registers.  Every other word only ever receives "row ^= pivot row where
+// bit t" -- a per-position linear map that does not feed back into the chain -- and is brought up to date afterwards by the other
+// waves in parallel (fwd_far_words below) from the per-step pivot rows left in ophi[].  A column whose pivot lies further away (the
+// first blocks of a shot, T still near the identity) switches the rest of the block to the full form: the far words are loaded,
+// caught up and carried along here (blk[5] = 1 tells the parallel stage not to transform them again).
+// (not inlined: inside the kernel its scalar registers compete with ~70 live kernel-wide values and the step loop fills with spill code)
 template <int WQ0>
-__device__ __forceinline__ void fwd_pivot_block(uint32_t *RL, int mw, int nb, int row, int rankH, int m, uint8_t *alive, const int *bcol,
-                                                const uint16_t *sidx, int *opa, int *opp, int *opt, uint16_t *pvcol, int *blk, int lane) {
-    constexpr int NW = 16 - WQ0;
+__device__ __noinline__ void fwd_pivot_block(LDSP uint32_t *RL, int mw, int nb, int row, int rankH, int m, LDSP uint8_t *alive, LDSP const int *bcol,
+                                             LDSP const uint16_t *sidx, LDSP int *opa, LDSP int *opp, LDSP int *opt, LDSP int *ophi,
+                                             LDSP uint16_t *pvcol, LDSP int *blk, int lane) {
+    constexpr int NW = 16 - WQ0, NN = NW < 2 ? NW : 2;
+    mw = uni(mw); nb = uni(nb); row = uni(row); rankH = uni(rankH); m = uni(m);
     uint32_t r[NW];
 #pragma unroll
-    for (int i = 0; i < NW; i++) r[i] = (WQ0 + i < mw) ? RL[(WQ0 + i) * 64 + lane] : 0u;
+    for (int i = 0; i < NW; i++) r[i] = (i < NN && WQ0 + i < mw) ? RL[(WQ0 + i) * 64 + lane] : 0u;
+    bool full = false;
     int lrow = row, nops = 0, anydep = 0;
     for (int t = 0; t < nb; t++) {
-        const int lq = lrow & 63;
-        const int pq = (lrow >> 6) - WQ0;                                                        // register of position lrow: 0 or 1
-        const unsigned long long keep = ~0ull << lq;
-        unsigned long long b0 = __ballot(((r[0] >> t) & 1u) != 0u), b1 = 0ull;
-        b0 = (pq == 0) ? (b0 & keep) : 0ull;
-        if (NW > 1) { b1 = __ballot(((r[NW > 1 ? 1 : 0] >> t) & 1u) != 0u); if (pq == 1) b1 &= keep; }
-        int pw = -1, lp = 0;
+        const int alq = lrow - 64 * WQ0;                                                         // 0 .. 127: position lrow relative to word WQ0
+        unsigned long long c0 = __ballot(((r[0] >> t) & 1u) != 0u), c1 = 0ull;
+        if (NN > 1) c1 = __ballot(((r[NN > 1 ? 1 : 0] >> t) & 1u) != 0u);
+        if (alq < 64) c0 &= ~0ull << alq; else { c0 = 0ull; c1 &= ~0ull << (alq - 64); }
+        int app = -1;                                                                            // pivot position relative to word WQ0
         uint32_t prow = 0u;
-        if (b0 != 0ull) { pw = 0; lp = __builtin_ctzll(b0); prow = (uint32_t)__builtin_amdgcn_readlane((int)r[0], lp); }
-        else if (b1 != 0ull) { pw = 1; lp = __builtin_ctzll(b1); prow = (uint32_t)__builtin_amdgcn_readlane((int)r[NW > 1 ? 1 : 0], lp); }
-        else {
+        if (c0 != 0ull) { app = __builtin_ctzll(c0); prow = (uint32_t)__builtin_amdgcn_readlane((int)r[0], app); }
+        else if (c1 != 0ull) { const int lp = __builtin_ctzll(c1); app = 64 + lp; prow = (uint32_t)__builtin_amdgcn_readlane((int)r[NN > 1 ? 1 : 0], lp); }
+        else if (NW > 2) {
+            if (!full) {                                                                         // bring the far words up to date, keep them from here on
+#pragma unroll
+                for (int i = 2; i < NW; i++) r[i] = (WQ0 + i < mw) ? RL[(WQ0 + i) * 64 + lane] : 0u;
+                for (int j = 0; j < nops; j++) {
+                    const int tj = __builtin_amdgcn_readfirstlane(opt[j]);
+                    const uint32_t ph = (uint32_t)__builtin_amdgcn_readfirstlane(ophi[j]);
+#pragma unroll
+                    for (int i = 2; i < NW; i++) r[i] ^= (uint32_t)__builtin_amdgcn_sbfe((int)r[i], tj, 1) & ph;
+                }
+                full = true;
+            }
 #pragma unroll
             for (int i = 2; i < NW; i++) {
-                if (pw < 0) {
+                if (app < 0) {
                     const unsigned long long bal = __ballot(((r[i] >> t) & 1u) != 0u);
-                    if (bal != 0ull) { pw = i; lp = __builtin_ctzll(bal); prow = (uint32_t)__builtin_amdgcn_readlane((int)r[i], lp); }
+                    if (bal != 0ull) { const int lp = __builtin_ctzll(bal); app = i * 64 + lp; prow = (uint32_t)__builtin_amdgcn_readlane((int)r[i], lp); }
                 }
             }
         }
-        if (pw < 0) {                                                                            // dependent on the pivots so far
+        if (app < 0) {                                                                           // dependent on the pivots so far
             if (lane == 0) alive[bcol[t]] = 0;
             anydep = 1;
             continue;
         }
-        const uint32_t arow = (pq == 0) ? (uint32_t)__builtin_amdgcn_readlane((int)r[0], lq) : (uint32_t)__builtin_amdgcn_readlane((int)r[NW > 1 ? 1 : 0], lq);
+        const uint32_t arow = (alq < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)r[0], alq)
+                                         : (uint32_t)__builtin_amdgcn_readlane((int)r[NN > 1 ? 1 : 0], alq - 64);
         const uint32_t low = (1u << t) - 1u;                                                     // finished columns keep their bits
         const uint32_t newA = (arow & low) | (prow & ~low), newP = (prow & low) | (arow & ~low);
         const uint32_t phi = prow & ~low & ~(1u << t);                                           // the pivot row on the later columns
-        const bool same = (pw == pq) && (lp == lq);
-        const uint32_t belowq = (lane > lq) ? phi : 0u;                                          // in the word of lrow only the lanes behind it take part
-        if (pw <= 1) {
-            if (pq == 0) {
-                uint32_t x = r[0];
-                if (pw == 0 && !same) x = (lane == lp) ? newP : x;
-                x = (lane == lq) ? newA : x;
-                r[0] = x ^ ((uint32_t)__builtin_amdgcn_sbfe((int)x, t, 1) & belowq);
-            }
-            if (NW > 1) {
-                uint32_t x = r[NW > 1 ? 1 : 0];
-                if (pw == 1 && !same) x = (lane == lp) ? newP : x;
-                if (pq == 1) x = (lane == lq) ? newA : x;
-                r[NW > 1 ? 1 : 0] = x ^ ((uint32_t)__builtin_amdgcn_sbfe((int)x, t, 1) & (pq == 1 ? belowq : phi));
-            }
 #pragma unroll
-            for (int i = 2; i < NW; i++) r[i] ^= (uint32_t)__builtin_amdgcn_sbfe((int)r[i], t, 1) & phi;
-        } else {
+        for (int i = 0; i < NN; i++) {                                                           // branch-free on relative positions; a word left of lrow
+            const int posn = i * 64 + lane;                                                      // has no position == app, == alq or > alq: it stays as it is
+            uint32_t x = r[i];
+            x = (posn == app) ? newP : x;
+            x = (posn == alq) ? newA : x;                                                        // (app == alq: no swap, the row keeps prow on the later columns)
+            r[i] = x ^ ((uint32_t)__builtin_amdgcn_sbfe((int)x, t, 1) & ((posn > alq) ? phi : 0u));
+        }
+        if (NW > 2 && full) {
 #pragma unroll
-            for (int i = 0; i < NW; i++) {
-                if (i >= pq) {
-                    uint32_t x = r[i];
-                    if (i == pw) x = (lane == lp) ? newP : x;
-                    if (i == pq) x = (lane == lq) ? newA : x;
-                    r[i] = x ^ ((uint32_t)__builtin_amdgcn_sbfe((int)x, t, 1) & (i == pq ? belowq : phi));
-                }
+            for (int i = 2; i < NW; i++) {
+                uint32_t x = r[i];
+                if ((app >> 6) == i) x = (lane == (app & 63)) ? newP : x;
+                r[i] = x ^ ((uint32_t)__builtin_amdgcn_sbfe((int)x, t, 1) & phi);
             }
         }
-        if (lane == 0) { opa[nops] = lrow; opp[nops] = (WQ0 + pw) * 64 + lp; opt[nops] = t; pvcol[lrow] = sidx[bcol[t]]; }
+        if (lane == 0) { opa[nops] = lrow; opp[nops] = 64 * WQ0 + app; opt[nops] = t; ophi[nops] = (int)phi; pvcol[lrow] = sidx[bcol[t]]; }
         nops++; lrow++;
         if (lrow >= rankH || lrow >= m) break;                                                   // full rank: the remaining columns cannot pivot
     }
 #pragma unroll
     for (int i = 0; i < NW; i++)
-        if (WQ0 + i < mw) RL[(WQ0 + i) * 64 + lane] = r[i];
-    if (lane == 0) { blk[1] = nops; blk[2] = anydep; }
+        if ((i < NN || full) && WQ0 + i < mw) RL[(WQ0 + i) * 64 + lane] = r[i];
+    if (lane == 0) { blk[1] = nops; blk[2] = anydep; blk[5] = full ? 1 : 0; }
+}
+
+template <int W0>
+__device__ __noinline__ void fwd_apply_block(LDSP unsigned long long *U, int m, int mw, int row0, int nops, int ppv, const uint32_t *maskg) {
+    m = uni(m); mw = uni(mw); row0 = uni(row0); nops = uni(nops); maskg = uni_ptr(maskg);
+    for (int q = threadIdx.x; q < m + 2; q += blockDim.x) {
+        if (q == m) continue;
+        fwd_apply_row<W0>(U, q, mw, row0, nops, ppv, maskg);
+    }
 }
 
 __global__ __launch_bounds__(1024) void osd0_fwd_kernel(OsdFwdArgs P) {
@@ -226,8 +256,8 @@ __global__ __launch_bounds__(1024) void osd0_fwd_kernel(OsdFwdArgs P) {
     uint16_t *pvcol = reinterpret_cast<uint16_t *>(lds + P.offPc);         // [m] pivot t sits at position t
     unsigned long long *R = reinterpret_cast<unsigned long long *>(lds + P.offR);       // [kFwdBlock][mw] reduced columns, column-major
     uint32_t *RL = reinterpret_cast<uint32_t *>(lds + P.offRL);            // [16][64] the same block, lane-major
-    int *blk = reinterpret_cast<int *>(lds + P.offBlk);                    // [0] nb, [1] nops, [2] anydep, [3] next c, [4] work item
-    int *bcol = blk + 8, *opa = bcol + kFwdBlock, *opp = opa + kFwdBlock, *opt = opp + kFwdBlock;
+    int *blk = reinterpret_cast<int *>(lds + P.offBlk);                    // [0] nb, [1] nops, [2] anydep, [3] next c, [4] work item, [5] far words carried by phase 2
+    int *bcol = blk + 8, *opa = bcol + kFwdBlock, *opp = opa + kFwdBlock, *opt = opp + kFwdBlock, *ophi = opt + kFwdBlock;
     uint16_t *ordw = P.ordws + (size_t)blockIdx.x * n;
     uint32_t *maskg = P.maskg + (size_t)blockIdx.x * (kFwdBlock * 32);
     const int brow = m + 1;                                                // U row that carries b
@@ -262,7 +292,7 @@ __global__ __launch_bounds__(1024) void osd0_fwd_kernel(OsdFwdArgs P) {
         }
         __syncthreads();
         int row = 0;
-        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0, c_back = 0;
+        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0, c_back = 0, c_ser = 0, d_full = 0;
         const long long t_sorted = OSD_CLOCK();
         bool finished = (P.rankH == 0);
         for (int base = 0; base < n && !finished; base += K) {
@@ -360,29 +390,42 @@ __global__ __launch_bounds__(1024) void osd0_fwd_kernel(OsdFwdArgs P) {
                 c_p1 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
                 // ---- phase 2: the block's pivots, one wave, no barrier (fwd_pivot_block) ----
                 if (wv == 0) {
-#define QLDPC_PIVOT_CASE(W) case W: fwd_pivot_block<W>(RL, mw, nb, row, P.rankH, m, alive, bcol, sidx, opa, opp, opt, pvcol, blk, lane); break;
+#define QLDPC_PIVOT_CASE(W) case W: fwd_pivot_block<W>((LDSP uint32_t *)RL, mw, nb, row, P.rankH, m, (LDSP uint8_t *)alive, (LDSP const int *)bcol, (LDSP const uint16_t *)sidx, (LDSP int *)opa, (LDSP int *)opp, (LDSP int *)opt, (LDSP int *)ophi, (LDSP uint16_t *)pvcol, (LDSP int *)blk, lane); break;
                     switch (row >> 6) {
                         QLDPC_PIVOT_CASE(0) QLDPC_PIVOT_CASE(1) QLDPC_PIVOT_CASE(2) QLDPC_PIVOT_CASE(3) QLDPC_PIVOT_CASE(4) QLDPC_PIVOT_CASE(5)
                         QLDPC_PIVOT_CASE(6) QLDPC_PIVOT_CASE(7) QLDPC_PIVOT_CASE(8) QLDPC_PIVOT_CASE(9) QLDPC_PIVOT_CASE(10) QLDPC_PIVOT_CASE(11)
                         QLDPC_PIVOT_CASE(12) QLDPC_PIVOT_CASE(13) QLDPC_PIVOT_CASE(14)
-                        default: fwd_pivot_block<15>(RL, mw, nb, row, P.rankH, m, alive, bcol, sidx, opa, opp, opt, pvcol, blk, lane); break;
+                        default: fwd_pivot_block<15>((LDSP uint32_t *)RL, mw, nb, row, P.rankH, m, (LDSP uint8_t *)alive, (LDSP const int *)bcol, (LDSP const uint16_t *)sidx, (LDSP int *)opa, (LDSP int *)opp, (LDSP int *)opt, (LDSP int *)ophi, (LDSP uint16_t *)pvcol, (LDSP int *)blk, lane); break;
                     }
 #undef QLDPC_PIVOT_CASE
                 }
                 __syncthreads();
+                const long long tpp = OSD_CLOCK();
+                c_ser += tpp - tp;
                 const int nops = blk[1], anydep = blk[2];
-                // elimination masks back to column-major words, straight into the global staging block the scalar loads of phase 3 read:
-                // A_k = (column t_k at the positions below a_k) ^ E_pp
+                d_full += blk[5];
+                // ---- all waves: wave w owns word w of the block.  Far words first receive the block's per-position map (see fwd_pivot_block);
+                // then every finished column goes back to a column-major word by ballot -- the elimination mask of its operation,
+                // A_k = (column t_k at the positions below a_k) ^ E_pp -- collected one operation per lane and stored with one instruction
+                // into the global staging block the scalar loads of phase 3 read.
                 if (wv < mw && nops > 0) {
-                    const uint32_t x = RL[wv * 64 + lane];
+                    uint32_t x = RL[wv * 64 + lane];
+                    const int v_t = opt[lane & 15], v_a = opa[lane & 15], v_p = opp[lane & 15], v_h = ophi[lane & 15];
+                    if (!blk[5] && wv >= (row >> 6) + 2) {
+                        for (int k = 0; k < nops; k++)
+                            x ^= (uint32_t)__builtin_amdgcn_sbfe((int)x, __builtin_amdgcn_readlane(v_t, k), 1) & (uint32_t)__builtin_amdgcn_readlane(v_h, k);
+                    }
+                    int mine_lo = 0, mine_hi = 0;
                     for (int k = 0; k < nops; k++) {
-                        const int t = opt[k], a = opa[k], pp = opp[k], wa = a >> 6;
+                        const int t = __builtin_amdgcn_readlane(v_t, k), a = __builtin_amdgcn_readlane(v_a, k), pp = __builtin_amdgcn_readlane(v_p, k);
+                        const int wa = a >> 6;
                         unsigned long long bal = __ballot(((x >> t) & 1u) != 0u);
                         if (wv < wa) bal = 0ull;
                         else if (wv == wa) bal &= ((~0ull << (a & 63)) << 1);
                         if (a != pp && wv == (pp >> 6)) bal ^= 1ull << (pp & 63);
-                        if (lane == 0) { maskg[k * 32 + 2 * wv] = (uint32_t)bal; maskg[k * 32 + 2 * wv + 1] = (uint32_t)(bal >> 32); }
+                        if (lane == k) { mine_lo = (int)(uint32_t)bal; mine_hi = (int)(uint32_t)(bal >> 32); }
                     }
+                    if (lane < nops) *reinterpret_cast<uint2 *>(maskg + lane * 32 + 2 * wv) = make_uint2((uint32_t)mine_lo, (uint32_t)mine_hi);
                 }
                 // the stores only have to reach this XCD's L2 (the vector L1 is write-through and the scalar cache reads from the same L2): wait for
                 // them, no agent-scope release -- __threadfence() writes the whole L2 back on this part (58 us per block, measured)
@@ -399,18 +442,16 @@ __global__ __launch_bounds__(1024) void osd0_fwd_kernel(OsdFwdArgs P) {
                     // v_readlane also reads lanes that sit out the row loop below
                     int ppv = opp[tid & 15];
                     asm volatile("" : "+v"(ppv));                          // pins the load here: the compiler may otherwise sink it into the divergent loop
-                    for (int q = tid; q < m + 2; q += T) {
-                        if (q == m) continue;
-                        switch (w0) {
-                            case 0: fwd_apply_row<0>(U, q, mw, row, nops, ppv, maskg); break;
-                            case 2: fwd_apply_row<2>(U, q, mw, row, nops, ppv, maskg); break;
-                            case 4: fwd_apply_row<4>(U, q, mw, row, nops, ppv, maskg); break;
-                            case 6: fwd_apply_row<6>(U, q, mw, row, nops, ppv, maskg); break;
-                            case 8: fwd_apply_row<8>(U, q, mw, row, nops, ppv, maskg); break;
-                            case 10: fwd_apply_row<10>(U, q, mw, row, nops, ppv, maskg); break;
-                            case 12: fwd_apply_row<12>(U, q, mw, row, nops, ppv, maskg); break;
-                            default: fwd_apply_row<14>(U, q, mw, row, nops, ppv, maskg); break;
-                        }
+                    LDSP unsigned long long *Ul = (LDSP unsigned long long *)U;
+                    switch (w0) {
+                        case 0: fwd_apply_block<0>(Ul, m, mw, row, nops, ppv, maskg); break;
+                        case 2: fwd_apply_block<2>(Ul, m, mw, row, nops, ppv, maskg); break;
+                        case 4: fwd_apply_block<4>(Ul, m, mw, row, nops, ppv, maskg); break;
+                        case 6: fwd_apply_block<6>(Ul, m, mw, row, nops, ppv, maskg); break;
+                        case 8: fwd_apply_block<8>(Ul, m, mw, row, nops, ppv, maskg); break;
+                        case 10: fwd_apply_block<10>(Ul, m, mw, row, nops, ppv, maskg); break;
+                        case 12: fwd_apply_block<12>(Ul, m, mw, row, nops, ppv, maskg); break;
+                        default: fwd_apply_block<14>(Ul, m, mw, row, nops, ppv, maskg); break;
                     }
                 }
                 row += nops;
@@ -481,7 +522,7 @@ __global__ __launch_bounds__(1024) void osd0_fwd_kernel(OsdFwdArgs P) {
             atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)row);
             atomicAdd(&P.dbg[4], (unsigned long long)(OSD_CLOCK() - t_start)); atomicAdd(&P.dbg[5], d_kills); atomicAdd(&P.dbg[6], d_blocks);
             atomicAdd(&P.dbg[8], (unsigned long long)(t_sorted - t_start)); atomicAdd(&P.dbg[9], c_p1); atomicAdd(&P.dbg[10], c_p2); atomicAdd(&P.dbg[11], c_p3);
-            atomicAdd(&P.dbg[12], c_kill); atomicAdd(&P.dbg[13], c_back);
+            atomicAdd(&P.dbg[12], c_kill); atomicAdd(&P.dbg[13], c_back); atomicAdd(&P.dbg[7], c_ser); atomicAdd(&P.dbg[14], d_full);
         }
         // ---- back-fill (osd.py:19-25): e[pivot col] = solution bit; solution = (hard + e) % 2 ----
         if (sol != hard) for (int j = tid; j < n; j += T) sol[j] = hard[j];
@@ -511,7 +552,7 @@ static bool plan_osd_fwd(const qldpc_graph *g, OsdFwdArgs &P, size_t &lds) {
     P.offPc = (int)off; off += (size_t)round_up((int64_t)g->m * 2, 16);
     P.offR = (int)off; off += (size_t)kFwdBlock * P.mw * 8;
     P.offRL = (int)off; off += (size_t)16 * 64 * 4;
-    P.offBlk = (int)off; off += (8 + 4 * kFwdBlock) * 4;
+    P.offBlk = (int)off; off += (8 + 5 * kFwdBlock) * 4;
     lds = off + 16;
     return lds <= 160 * 1024;
 }

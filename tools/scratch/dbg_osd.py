@@ -16,7 +16,7 @@ for (m, n, dens) in ((20, 60, 0.15), (31, 100, 0.1), (33, 100, 0.1), (40, 120, 0
     hard = (rng.random((B, n)) < 0.1).astype(np.int8)
     want = np.stack([oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)])
     res = {}
-    for name, fl in (("fwd", 0), ("fwd_nokill", L.FLAG_OSD_NOKILL), ("legacy", L.FLAG_OSD_LEGACY)):
+    for name, fl in (("fwd", L.FLAG_OSD_FWD), ("fwd_nokill", L.FLAG_OSD_FWD | L.FLAG_OSD_NOKILL), ("legacy", 0)):
         sol = L.osd0_batch(graph, synd, llr, hard, flags=fl)
         res[name] = int((sol != want).any(1).sum())
     cd = int(np.diff(np.concatenate([[0], np.cumsum(Hd.sum(0))])).max())
