@@ -111,11 +111,19 @@ struct qldpc_graph {
     // ELL (slot-major) views for the workgroup-per-shot kernel: coalesced index loads across rows / columns
     uint16_t *d_ell_col = nullptr;   // [round_up(max_row_deg, 8)][m]  column of the k-th edge of row i; unused slots hold column 0
     uint32_t *d_ell_var = nullptr;   // [max_col_deg][n]  (row << 8) | position-in-row of the d-th edge of column j (ascending rows)
+    // the same views with rows / columns handed to threads in DEGREE order (stable, descending): a wave's rows (columns) then have one
+    // degree and its edge loop has no idle lanes.  Check state and index entries are in row-SLOT space; posteriors stay in column space.
+    int32_t *d_row_of_slot = nullptr, *d_col_of_slot = nullptr;   // [m], [n]
+    uint8_t *d_deg_of_rslot = nullptr, *d_deg_of_row = nullptr;      // [m]
+    uint16_t *d_deg_of_cslot = nullptr, *d_deg_of_col = nullptr;     // [n]
+    uint16_t *d_ell_col_s = nullptr; // [round_up(max_row_deg, 8)][m] indexed by row slot
+    uint32_t *d_ell_var_s = nullptr; // [max_col_deg][n] indexed by column slot: (row slot << 8) | position-in-row, ascending ROW order
+    int32_t *d_identity = nullptr;   // [max(m, n)] 0, 1, 2, ... (the natural-order "permutation")
     // Device workspaces of the decode / OSD kernels.  `mu` guards the bookkeeping while launches are enqueued; the buffers themselves
     // are protected in STREAM order: every user calls ws_acquire(stream) before its launches and ws_release(stream) after them, so a
     // launch on another stream first waits (hipStreamWaitEvent) for the previous user of the workspaces to finish.
     mutable std::mutex mu;
-    mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_misc, ws_queue, ws_list;
+    mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_misc, ws_queue, ws_list, ws_prior;
     mutable hipEvent_t ws_event = nullptr;
     mutable hipStream_t ws_stream = nullptr;
     mutable bool ws_used = false;

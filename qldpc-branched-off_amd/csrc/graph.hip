@@ -202,6 +202,41 @@ QLDPC_EXPORT int qldpc_graph_create(int m, int n, const int32_t *indptr, const i
             }
         rc = upload(&g->d_ell_col, ec);
         if (rc == QLDPC_OK) rc = upload(&g->d_ell_var, ev);
+        // degree-ordered views (stable sort, descending degree)
+        std::vector<int32_t> ros(std::max(m, 1)), cos(std::max(n, 1)), slot_of_row(std::max(m, 1));
+        for (int i = 0; i < m; i++) ros[i] = i;
+        for (int j = 0; j < n; j++) cos[j] = j;
+        std::stable_sort(ros.begin(), ros.begin() + m, [&](int a, int b) { return indptr[a + 1] - indptr[a] > indptr[b + 1] - indptr[b]; });
+        std::stable_sort(cos.begin(), cos.begin() + n, [&](int a, int b) { return g->colptr[a + 1] - g->colptr[a] > g->colptr[b + 1] - g->colptr[b]; });
+        for (int s = 0; s < m; s++) slot_of_row[ros[s]] = s;
+        std::vector<uint8_t> drs(std::max(m, 1), 0), dr(std::max(m, 1), 0);
+        std::vector<uint16_t> dcs(std::max(n, 1), 0), dc(std::max(n, 1), 0);
+        for (int s = 0; s < m; s++) { drs[s] = (uint8_t)(indptr[ros[s] + 1] - indptr[ros[s]]); dr[s] = (uint8_t)(indptr[s + 1] - indptr[s]); }
+        for (int s = 0; s < n; s++) { dcs[s] = (uint16_t)std::min(g->colptr[cos[s] + 1] - g->colptr[cos[s]], 65535); dc[s] = (uint16_t)std::min(g->colptr[s + 1] - g->colptr[s], 65535); }
+        std::vector<uint16_t> ecs(ec.size(), 0);
+        std::vector<uint32_t> evs(ev.size(), 0xFFFFFFFFu);
+        for (int s = 0; s < m; s++) {
+            const int i = ros[s];
+            for (int e = indptr[i]; e < indptr[i + 1]; e++) ecs[(size_t)(e - indptr[i]) * m + s] = (uint16_t)indices[e];
+        }
+        for (int s = 0; s < n; s++) {
+            const int j = cos[s];
+            for (int k = g->colptr[j]; k < g->colptr[j + 1]; k++) {
+                const int row = g->rowidx[k], pos = g->csc2csr[k] - indptr[row];
+                evs[(size_t)(k - g->colptr[j]) * n + s] = ((uint32_t)slot_of_row[row] << 8) | (uint32_t)pos;
+            }
+        }
+        std::vector<int32_t> ident(std::max(std::max(m, n), 1));
+        for (size_t i = 0; i < ident.size(); i++) ident[i] = (int32_t)i;
+        if (rc == QLDPC_OK) rc = upload(&g->d_row_of_slot, ros);
+        if (rc == QLDPC_OK) rc = upload(&g->d_col_of_slot, cos);
+        if (rc == QLDPC_OK) rc = upload(&g->d_deg_of_rslot, drs);
+        if (rc == QLDPC_OK) rc = upload(&g->d_deg_of_cslot, dcs);
+        if (rc == QLDPC_OK) rc = upload(&g->d_deg_of_row, dr);
+        if (rc == QLDPC_OK) rc = upload(&g->d_deg_of_col, dc);
+        if (rc == QLDPC_OK) rc = upload(&g->d_ell_col_s, ecs);
+        if (rc == QLDPC_OK) rc = upload(&g->d_ell_var_s, evs);
+        if (rc == QLDPC_OK) rc = upload(&g->d_identity, ident);
     }
     if (rc != QLDPC_OK) { qldpc_graph_destroy(g); return rc; }
     *out = g;
@@ -216,6 +251,10 @@ QLDPC_EXPORT void qldpc_graph_destroy(qldpc_graph *g) {
     if (g->d_ell_col) (void)hipFree(g->d_ell_col);
     if (g->d_ell_var) (void)hipFree(g->d_ell_var);
     if (g->d_col_rows) (void)hipFree(g->d_col_rows);
+    for (void *p : {(void *)g->d_row_of_slot, (void *)g->d_col_of_slot, (void *)g->d_deg_of_rslot, (void *)g->d_deg_of_cslot, (void *)g->d_deg_of_row,
+                    (void *)g->d_deg_of_col, (void *)g->d_ell_col_s, (void *)g->d_ell_var_s, (void *)g->d_identity})
+        if (p) (void)hipFree(p);
+    g->ws_prior.release();
     g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_list.release();
     for (auto &e : g->alpha_cache) { if (e.dev) (void)hipFree(e.dev); if (e.pinned) (void)hipHostFree(e.pinned); if (e.ready) (void)hipEventDestroy(e.ready); }
     if (g->ws_event) (void)hipEventDestroy(g->ws_event);

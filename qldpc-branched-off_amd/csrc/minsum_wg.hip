@@ -21,9 +21,14 @@ namespace qldpc {
 
 struct WgArgs {
     int m, n, max_iter, fixed, rdeg, cdeg, nfcheck;
-    const int32_t *indptr;
-    const uint16_t *ell_col;
-    const uint32_t *ell_var;
+    // rows / columns are handed to threads by SLOT (degree order, or the natural order with QLDPC_FLAG_WG_ROWMAJOR); check state and the
+    // entries of ell_var live in row-slot space, posteriors in column space
+    const int32_t *row_of_slot, *col_of_slot;
+    const uint8_t *degr;           // [m] degree of the row in slot s
+    const uint16_t *degc;          // [n] degree of the column in slot c
+    const uint16_t *ell_col;       // [round_up(rdeg, 8)][m] by row slot
+    const uint32_t *ell_var;       // [cdeg][n] by column slot
+    const double *prior_s;         // [n] prior by column slot
     int64_t B;
     const int8_t *synd; const double *prior, *alpha;
     double clip;
@@ -64,9 +69,9 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
             // ---------------- check pass ----------------
             if (A.fixed || !done) {
                 const double alpha = (it < max_iter) ? A.alpha[it] : 0.0;
-                for (int i = tid; i < m; i += T) {
-                    const int deg = A.indptr[i + 1] - A.indptr[i];
-                    const bool csyn = A.synd[b * m + i] & 1;
+                for (int i = tid; i < m; i += T) {                                           // i = row slot
+                    const int deg = A.degr[i];
+                    const bool csyn = A.synd[b * m + A.row_of_slot[i]] & 1;
                     double p1p = 0.0, p2p = 0.0;
                     unsigned long long ip = 0ull;
                     if (it > 0 && deg > 0) { const double2 t = SP[i]; p1p = t.x; p2p = t.y; ip = SI[i]; }
@@ -121,10 +126,11 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
             if (it == max_iter) break;
             if (tid == 0) unsat[(it + 1) & 1] = 0;
             // ---------------- variable pass: values_it ----------------
-            for (int j = tid; j < n; j += T) {
+            for (int c = tid; c < n; c += T) {                                               // c = column slot
+                const int j = A.col_of_slot[c];
                 double s = 0.0;                                                              // kernels.py:279
                 for (int d = 0; d < A.cdeg; d++) {
-                    const uint32_t e = A.ell_var[(size_t)d * n + j];
+                    const uint32_t e = A.ell_var[(size_t)d * n + c];
                     if (e == 0xFFFFFFFFu) break;
                     const int i = (int)(e >> 8), k = (int)(e & 255u);
                     const double2 pp = SP[i];
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
                     const double mag = (k == (int)((inf >> 56) & 127)) ? pp.y : pp.x;
                     s += ((bool)((inf >> 63) & 1) != (bool)((inf >> k) & 1)) ? -mag : mag;   // kernels.py:316, ascending check order
                 }
-                V[j] = s + A.prior[j];                                                       // kernels.py:320
+                V[j] = s + A.prior_s[c];                                                     // kernels.py:320
             }
             __syncthreads();
         }
@@ -162,48 +168,63 @@ __device__ __forceinline__ double flip_sign(double x, uint32_t signword) { retur
 // One row of the check pass, edges taken 8 at a time: the 8 index loads (slot-major table, coalesced), then the 8 posterior
 // gathers from LDS are issued back to back before the dependent min/sign chain starts, so their latencies overlap instead
 // of adding up per edge (the per-edge loop the compiler emits otherwise waits for memory twice per edge).
+// FULL: every lane of the wave has all 8 edges of this chunk (rows are handed out in degree order, so that is the rule, not the
+// exception): no per-edge predicate, which is 4 of the ~21 instructions an edge costs.
+template <bool NANSEL, bool FIRST, bool DAMP, bool FULL>
+__device__ __forceinline__ void wg_lean_chunk(const uint16_t *__restrict__ ec, int m, const double *__restrict__ V, int deg, int k0, double p1s, double p2s,
+                                              uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, double damping, double one_minus_d,
+                                              double *__restrict__ qo, bool store_q, bool &par, double &min1, double &min2, int &arg, uint32_t &nlo,
+                                              uint32_t &nhi) {
+    uint32_t c[8];
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) c[u] = ec[(size_t)(k0 + u) * m];                            // table rows are padded to a multiple of 8 with column 0
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = V[c[u]];
+    double qprev[8];
+    if (DAMP && !FIRST) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) qprev[u] = qo[(size_t)(k0 + u) * m];                     // slab rows are padded to a multiple of 8 slots
+    }
+    const uint32_t pw = (k0 < 32) ? (ip_lo >> k0) : (ip_hi >> (k0 - 32));                    // previous sign bits of this chunk
+    const int au = argp - k0;
+    uint32_t cb = 0u;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        if (FULL || k0 + u < deg) {
+            par ^= (v[u] < 0.0);                                                             // kernels.py:349,356
+            double x = v[u];
+            if (!FIRST) {
+                const double mag = (u == au) ? p2s : p1s;                                    // kernels.py:313 (already carries the row sign)
+                const double r = flip_sign(mag, (pw >> u) << 31);                            // R_{it-1}[e], kernels.py:311-314
+                x = v[u] - r;                                                                // kernels.py:325
+                if (NANSEL) x = (x != x) ? 0.0 : x;                                          // kernels.py:328-329
+                x = wmax_s(wmin_s(x, clip), nclip);                                          // kernels.py:330-333
+                if (DAMP) x = wmax_s(wmin_s(damping * x + one_minus_d * qprev[u], clip), nclip);   // kernels.py:336-342 (finite operands)
+            }
+            if (DAMP && store_q) qo[(size_t)(k0 + u) * m] = x;                               // kernels.py:344-345
+            // without damping x is never -0.0 or NaN here (see above); a damped x may underflow to -0.0, which counts as positive
+            cb |= (DAMP ? (x < 0.0 ? 1u : 0u) : ((uint32_t)__double2hiint(x) >> 31)) << u;
+            if (fabs(x) < min1) arg = k0 + u;                                                // kernels.py:301-304 (strict: first minimum wins)
+            min2 = wmin(min2, wmax_abs2(min1, x));                                           // kernels.py:302,305-306
+            min1 = wmin_abs2(min1, x);
+        }
+    }
+    if (k0 < 32) nlo |= cb << k0; else nhi |= cb << (k0 - 32);
+}
+
 template <bool NANSEL, bool FIRST, bool DAMP>
 __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int m, const double *__restrict__ V, int deg, double p1s, double p2s,
                                             uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, double damping, double one_minus_d,
                                             double *__restrict__ qo, bool store_q, bool &par, double &min1, double &min2, int &arg, uint32_t &nlo,
                                             uint32_t &nhi) {
     for (int k0 = 0; k0 < deg; k0 += 8) {
-        uint32_t c[8];
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) c[u] = ec[(size_t)(k0 + u) * m];                        // table rows are padded to a multiple of 8 with column 0
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = V[c[u]];
-        double qprev[8];
-        if (DAMP && !FIRST) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) qprev[u] = qo[(size_t)(k0 + u) * m];                 // slab rows are padded to a multiple of 8 slots
-        }
-        const uint32_t pw = (k0 < 32) ? (ip_lo >> k0) : (ip_hi >> (k0 - 32));                // previous sign bits of this chunk
-        const int au = argp - k0;
-        uint32_t cb = 0u;
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (k0 + u < deg) {
-                par ^= (v[u] < 0.0);                                                         // kernels.py:349,356
-                double x = v[u];
-                if (!FIRST) {
-                    const double mag = (u == au) ? p2s : p1s;                                // kernels.py:313 (already carries the row sign)
-                    const double r = flip_sign(mag, (pw >> u) << 31);                        // R_{it-1}[e], kernels.py:311-314
-                    x = v[u] - r;                                                            // kernels.py:325
-                    if (NANSEL) x = (x != x) ? 0.0 : x;                                      // kernels.py:328-329
-                    x = wmax_s(wmin_s(x, clip), nclip);                                      // kernels.py:330-333
-                    if (DAMP) x = wmax_s(wmin_s(damping * x + one_minus_d * qprev[u], clip), nclip);   // kernels.py:336-342 (finite operands)
-                }
-                if (DAMP && store_q) qo[(size_t)(k0 + u) * m] = x;                           // kernels.py:344-345
-                // without damping x is never -0.0 or NaN here (see above); a damped x may underflow to -0.0, which counts as positive
-                cb |= (DAMP ? (x < 0.0 ? 1u : 0u) : ((uint32_t)__double2hiint(x) >> 31)) << u;
-                if (fabs(x) < min1) arg = k0 + u;                                            // kernels.py:301-304 (strict: first minimum wins)
-                min2 = wmin(min2, wmax_abs2(min1, x));                                       // kernels.py:302,305-306
-                min1 = wmin_abs2(min1, x);
-            }
-        }
-        if (k0 < 32) nlo |= cb << k0; else nhi |= cb << (k0 - 32);
+        if (__all(k0 + 8 <= deg))
+            wg_lean_chunk<NANSEL, FIRST, DAMP, true>(ec, m, V, deg, k0, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, damping, one_minus_d, qo, store_q, par, min1,
+                                                     min2, arg, nlo, nhi);
+        else
+            wg_lean_chunk<NANSEL, FIRST, DAMP, false>(ec, m, V, deg, k0, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, damping, one_minus_d, qo, store_q, par, min1,
+                                                      min2, arg, nlo, nhi);
     }
 }
 
@@ -219,7 +240,8 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     const double clip = A.clip, nclip = -A.clip, damping = A.damping, one_minus_d = 1.0 - A.damping;
     double *Qo = DAMP ? A.qold + (size_t)blockIdx.x * A.qstride : nullptr;
     const ClkStamp clk0 = clk_begin(A.clk);
-    const int deg_own = (tid < m) ? A.indptr[tid + 1] - A.indptr[tid] : 0;                   // the thread's first row, constant over shots
+    const int deg_own = (tid < m) ? (int)A.degr[tid] : 0;                                    // the thread's first row slot, constant over shots
+    const int row_own = (tid < m) ? A.row_of_slot[tid] : 0;
     if (tid == 0) { SP[m] = make_double2(0.0, 0.0); SI[m] = make_uint2(0u, 0u); }            // dummy check read by padded column slots
 
     for (;;) {
@@ -229,15 +251,15 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
         if (b >= A.B) break;
         for (int j = tid; j < n; j += T) V[j] = A.prior[j];                                  // Q_{-1} = prior[col] (kernels.py:263-265)
         if (tid < 2) unsat[tid] = 0;
-        const bool csyn_own = (tid < m) ? (A.synd[b * m + tid] & 1) : false;
+        const bool csyn_own = (tid < m) ? (A.synd[b * m + row_own] & 1) : false;
         bool done = false;
         __syncthreads();
         for (int it = 0; it <= max_iter; it++) {
             if (A.fixed || !done) {
                 const double alpha = (it < max_iter) ? A.alpha[it] : 0.0;
-                for (int i = tid; i < m; i += T) {
-                    const int deg = (i == tid) ? deg_own : A.indptr[i + 1] - A.indptr[i];
-                    const bool csyn = (i == tid) ? csyn_own : (bool)(A.synd[b * m + i] & 1);
+                for (int i = tid; i < m; i += T) {                                           // i = row slot
+                    const int deg = (i == tid) ? deg_own : (int)A.degr[i];
+                    const bool csyn = (i == tid) ? csyn_own : (bool)(A.synd[b * m + A.row_of_slot[i]] & 1);
                     bool par = csyn;
                     double min1 = INFINITY, min2 = INFINITY;
                     int arg = 127;
@@ -281,15 +303,30 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
             if (it == max_iter) break;
             if (tid == 0) unsat[(it + 1) & 1] = 0;
             // variable pass: values_it.  Same batching: the column's edge slots are loaded 4 at a time, then the 4 check states.
-            for (int j = tid; j < n; j += T) {
-                const double pr = A.prior[j];
+            for (int c = tid; c < n; c += T) {                                               // c = column slot
+                const int j = A.col_of_slot[c], cdj = A.degc[c];
+                const double pr = A.prior_s[c];
                 double s = 0.0;                                                              // kernels.py:279
-                for (int d0 = 0; d0 < A.cdeg; d0 += 4) {
+                for (int d0 = 0; d0 < cdj; d0 += 4) {                                        // (slots of one degree share a wave: no idle chunk)
                     uint32_t e[4];
                     double2 pp[4];
                     uint2 si[4];
+                    if (__all(d0 + 4 <= cdj)) {                                              // every lane has all four edges: no predicates
 #pragma unroll
-                    for (int u = 0; u < 4; u++) e[u] = (d0 + u < A.cdeg) ? A.ell_var[(size_t)(d0 + u) * n + j] : 0xFFFFFFFFu;
+                        for (int u = 0; u < 4; u++) e[u] = A.ell_var[(size_t)(d0 + u) * n + c];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { const uint32_t i = e[u] >> 8; pp[u] = SP[i]; si[u] = SI[i]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t k = e[u] & 255u;
+                            const double mag = (k == (si[u].y >> 24)) ? pp[u].y : pp[u].x;
+                            const uint32_t w = (k < 32u) ? (si[u].x >> k) : (si[u].y >> (k - 32u));
+                            s += flip_sign(mag, w << 31);                                    // kernels.py:316, ascending check order
+                        }
+                        continue;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) e[u] = (d0 + u < A.cdeg) ? A.ell_var[(size_t)(d0 + u) * n + c] : 0xFFFFFFFFu;
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const uint32_t i = min(e[u] >> 8, (uint32_t)m);                      // empty slot -> the dummy check
@@ -314,6 +351,11 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     clk_end(A.clk, clk0);
 }
 
+__global__ void permute_prior_kernel(int n, const int32_t *__restrict__ col_of_slot, const double *__restrict__ prior, double *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) out[c] = prior[col_of_slot[c]];
+}
+
 static size_t wg_lds_bytes(const qldpc_graph *g, bool vg, int &offP, int &offI, int &offF) {
     offP = vg ? 0 : (int)round_up((int64_t)g->n * 8, 16);
     offI = offP + (g->m + 1) * 16;     // one spare check state: the target of empty column slots in the lean kernel
@@ -324,7 +366,7 @@ static size_t wg_lds_bytes(const qldpc_graph *g, bool vg, int &offP, int &offI, 
 // 0: not supported, 1: everything in LDS, 2: check states in LDS, posteriors in global memory
 static int wg_mode(const qldpc_graph *g, double damping, int flags) {
     (void)damping;                      // damping != 1 keeps Q_old in an HBM/L2 slab
-    if (!g->d_ell_col || !g->d_ell_var) return 0;
+    if (!g->d_ell_col || !g->d_ell_var || !g->d_ell_col_s || !g->d_ell_var_s) return 0;
     if (g->m <= 0 || g->n <= 0 || g->max_row_deg > 56) return 0;
     int a, b, c;
     if (wg_lds_bytes(g, false, a, b, c) <= 160 * 1024 && !(flags & QLDPC_FLAG_WG_VGLOBAL)) return 1;
@@ -338,7 +380,13 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     WgArgs A;
     A.m = g->m; A.n = g->n; A.max_iter = max_iter; A.fixed = (flags & QLDPC_FLAG_FIXED_ITERS) ? 1 : 0;
     A.rdeg = g->max_row_deg; A.cdeg = g->max_col_deg; A.nfcheck = (flags & QLDPC_FLAG_INTERNAL_PRIOR_FINITE) ? 0 : 1;
-    A.indptr = g->d_indptr; A.ell_col = g->d_ell_col; A.ell_var = g->d_ell_var;
+    const bool natural = (flags & QLDPC_FLAG_WG_ROWMAJOR) != 0;
+    A.row_of_slot = natural ? g->d_identity : g->d_row_of_slot;
+    A.col_of_slot = natural ? g->d_identity : g->d_col_of_slot;
+    A.degr = natural ? g->d_deg_of_row : g->d_deg_of_rslot;
+    A.degc = natural ? g->d_deg_of_col : g->d_deg_of_cslot;
+    A.ell_col = natural ? g->d_ell_col : g->d_ell_col_s;
+    A.ell_var = natural ? g->d_ell_var : g->d_ell_var_s;
     A.B = B; A.synd = d_synd; A.prior = d_prior; A.alpha = d_alpha; A.clip = clip;
     A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;
     const bool vg = (wg_mode(g, damping, flags) == 2), damp = (damping != 1.0);
@@ -352,6 +400,9 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     QLDPC_HIP_TRY(hipMemsetAsync(g->ws_queue.p, 0, 16, stream));
     A.queue = g->ws_queue.as<int>();
     A.clk = g->clk_probe;
+    if ((rcq = g->ws_prior.ensure((size_t)g->n * 8)) != QLDPC_OK) return rcq;                // the prior in column-slot order (per launch: it is an input)
+    hipLaunchKernelGGL(permute_prior_kernel, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, stream, g->n, A.col_of_slot, d_prior, g->ws_prior.as<double>());
+    A.prior_s = g->ws_prior.as<double>();
     A.vglobal = nullptr; A.qold = nullptr; A.qstride = 0; A.damping = damping;
     if (vg) {
         if ((rcq = g->ws_vals.ensure((size_t)grid * g->n * 8)) != QLDPC_OK) return rcq;
