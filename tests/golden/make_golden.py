@@ -284,6 +284,51 @@ def gen_gf2():
     save("gf2_elimination", **out)
 
 
+def gen_bb256():
+    """SURVEY 8c asked for >= 256 sampled syndromes per (code, p) point: Hx of the three headline codes at p = 0.005 / 0.02 / 0.05, full
+    decoder defaults (maxIter 50, dynamic alpha).  Bit arrays are stored packed, the posteriors in full."""
+    rng = np.random.default_rng(20260901)
+    out = {}
+    for tag in ("bb72", "bb144", "bb288"):
+        d = load_code(tag)
+        H = d["Hx"]
+        Hc = csr_of(H)
+        m, n = H.shape
+        out[f"{tag}_shape"] = np.array([m, n], np.int64)
+        for p in (0.005, 0.02, 0.05):
+            ptag = f"{tag}_p{int(round(p * 1000)):03d}"
+            errs = (rng.random((256, n)) < p).astype(np.int8)
+            synds = (errs @ H.T % 2).astype(np.int8)
+            prior = np.full(n, np.log((1 - p) / p))
+            E, C, V, I = batch_sparse(Hc, synds, prior, maxIter=50, alpha=1.0, alpha_mode="dynamical")
+            out[f"{ptag}_errors"] = np.packbits(errs.astype(np.uint8), axis=1, bitorder="little")
+            out[f"{ptag}_hard"] = np.packbits(E.astype(np.uint8), axis=1, bitorder="little")
+            out[f"{ptag}_conv"], out[f"{ptag}_llr"], out[f"{ptag}_iter"] = C, V, I
+            print(f"    {ptag}: converged {int(C.sum())}/256, mean iterations {float(I.mean() + 1):.2f}")
+    save("bb_256", **out)
+
+
+def gen_gf2_big():
+    """The production-size elimination SURVEY 8c asked for: HdecZ of the [[144,12,12]] x 12-cycle experiment (1008 x 8785) with its
+    columns in the |llr| order of a non-converged golden decode, through gf2_elimination_packed (kernels.py:48-106), in place.
+    Inputs are reproducible from shipped data: H = data/circ144_p005.npz, the column order and right-hand side stored here."""
+    g = np.load(os.path.join(HERE, "circ144_decode.npz"))
+    path, code, cycles, p = CACHE["circ144"]
+    M = np.load(os.path.join(REF, path))
+    H = np.asarray(M["HdecZ"]).astype(np.int64)
+    case = int(g["Z_osd_cases"][0])
+    order = np.asarray(g["Z_osd_ordering"][0], np.int64)
+    hard = np.asarray(g["Z_err"][case], np.int64)
+    synd = np.asarray(g["Z_syndromes"][case], np.int64)
+    b = (synd + H @ hard) % 2                                       # osd.py:8-9
+    A = H[:, order].astype(np.int64)                                # osd.py:13-15
+    t0 = time.time()
+    Ap, br, pr, pc = K.gf2_elimination_packed(A, b.copy())
+    print(f"    1008 x 8785 elimination in pure Python: {time.time() - t0:.0f}s, rank {len(pr)}")
+    save("gf2_big", ordering=order.astype(np.int32), b=b.astype(np.uint8), A_packed_red=np.asarray(Ap, np.uint64), b_red=np.asarray(br).astype(np.uint8),
+         pivot_rows=np.asarray(pr, np.int64), pivot_cols=np.asarray(pc, np.int64), case=np.int64(case))
+
+
 # --------------------------------------------------------------------------- circuit level
 def build_circuit(tag):
     path, code, cycles, p = CACHE[tag]
@@ -586,7 +631,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["data", "steane", "bb", "core", "gf2", "circ72", "circ144", "estimators", "osdw"]
+    todo = a.only.split(",") if a.only else ["data", "steane", "bb", "core", "gf2", "circ72", "circ144", "estimators", "osdw", "bb256", "gf2big"]
     t0 = time.time()
     if "data" in todo:
         print("[data]"); pack_data()
@@ -608,6 +653,10 @@ def main():
         print("[estimators]"); gen_estimators()
     if "osdw" in todo:
         print("[osdw]"); gen_osdw()
+    if "bb256" in todo:
+        print("[bb256]"); gen_bb256()
+    if "gf2big" in todo:
+        print("[gf2big]"); gen_gf2_big()
     print(f"done in {time.time() - t0:.0f}s")
 
 

@@ -218,6 +218,51 @@ def test_reference_named_api(L, golden):
         performMinSum_Symmetric(H, g["bpdrv_syndromes"][0], g["bpdrv_prior"], alpha_mode="nope")
 
 
+def test_bb_golden_256(L, golden):
+    """>= 256 reference-decoded syndromes per (code, p) point: Hx of [[72,12,6]] / [[144,12,12]] / [[288,12,18]] at p = 0.005 / 0.02 /
+    0.05, decoder defaults, all three resident / streaming kernels; bit-identical posteriors."""
+    from qldpc_amd.data import load_code
+    g = golden("bb_256")
+    for tag in ("bb72", "bb144", "bb288"):
+        c = load_code(tag)
+        m, n = (int(x) for x in g[f"{tag}_shape"])
+        graph = L.Graph(c["Hx_indptr"], c["Hx_indices"], n)
+        for p in (0.005, 0.02, 0.05):
+            k = f"{tag}_p{int(round(p * 1000)):03d}"
+            errs = np.unpackbits(g[f"{k}_errors"], axis=1, bitorder="little")[:, :n].astype(np.int8)
+            hard = np.unpackbits(g[f"{k}_hard"], axis=1, bitorder="little")[:, :n].astype(np.int8)
+            synd = L.gf2_spmv_batch(graph, errs)                                     # a6 on the device: s = H e
+            assert np.array_equal(synd, (errs.astype(np.int64) @ c["Hx"].T.astype(np.int64) % 2).astype(np.int8))
+            prior = np.full(n, np.log((1 - p) / p))
+            for fl in (0, L.FLAG_KERNEL_GENERIC, L.FLAG_KERNEL_STREAM, L.FLAG_FIXED_ITERS):
+                err, conv, llr, it = L.minsum_decode_batch(graph, synd, prior, 50, "dynamical", 1.0, flags=fl)
+                assert np.array_equal(err, hard) and np.array_equal(conv.astype(bool), g[f"{k}_conv"].astype(bool)), (k, fl)
+                assert np.array_equal(it, g[f"{k}_iter"]) and np.array_equal(llr, g[f"{k}_llr"]), (k, fl)
+
+
+def test_gf2_elimination_production_size(L, golden):
+    """The 1008 x 8785 instance of the [[144,12,12]] x 12-cycle experiment, columns in the |llr| order of a non-converged decode, through
+    gf2_elimination_packed (kernels.py:48-106) in place: reduced packed matrix, right-hand side and pivots equal the reference's."""
+    from qldpc_amd.decoding import kernels as K
+    from qldpc_amd.data import load_circuit_matrices
+    g, gd = golden("gf2_big"), golden("circ144_decode")
+    d = load_circuit_matrices("circ144")
+    m, n = (int(x) for x in d["HdecZ_shape"])
+    H = np.zeros((m, n), np.int64)
+    ip, ix = d["HdecZ_indptr"], d["HdecZ_indices"]
+    for i in range(m):
+        H[i, ix[ip[i]:ip[i + 1]]] = 1
+    case = int(g["case"])
+    b0 = (gd["Z_syndromes"][case].astype(np.int64) + H @ gd["Z_err"][case].astype(np.int64)) % 2
+    assert np.array_equal(b0, g["b"])                                                # osd.py:8-9 reproduced from the shipped data
+    A = H[:, g["ordering"].astype(np.int64)].copy()
+    b = b0.copy()
+    Ap, bp, pr, pc = K.gf2_elimination_packed(A, b)
+    assert bp is b                                                                   # in place, like the reference
+    assert np.array_equal(pr, g["pivot_rows"]) and np.array_equal(pc, g["pivot_cols"]) and np.array_equal(b, g["b_red"])
+    assert np.array_equal(np.asarray(Ap, np.uint64), g["A_packed_red"])
+
+
 def test_gf2_elimination_golden(L, golden):
     from qldpc_amd.decoding import kernels as K
     g = golden("gf2_elimination")
@@ -623,10 +668,12 @@ def test_full_size_properties(L, oracle):
         counters are mutually consistent; an oracle-checked prefix anchors the stream itself."""
     from qldpc_amd.data import load_code
     T = L.TALLY
-    for tag, p, N in (("bb144", 0.005, 10_000_000), ("bb72", 0.005, 1_000_000), ("bb288", 0.004, 2_000_000), ("bb288", 0.006, 2_000_000)):
+    # BASELINE configs 3, 2 (quoted at batch = 4096) and 4 (all three points of the p-sweep)
+    for tag, p, N, batch in (("bb144", 0.005, 10_000_000, 1 << 20), ("bb72", 0.005, 1_000_000, 4096), ("bb288", 0.004, 2_000_000, 1 << 20),
+                             ("bb288", 0.005, 2_000_000, 1 << 20), ("bb288", 0.006, 2_000_000, 1 << 20)):
         c = load_code(tag)
         graph = L.graph_for(c["Hx_indptr"], c["Hx_indices"], c["n"])
-        plan = L.CodeCapacityPlan(graph, c["Lx"], p, max_iter=50, use_osd=True, batch=1 << 20)
+        plan = L.CodeCapacityPlan(graph, c["Lx"], p, max_iter=50, use_osd=True, batch=batch)
         plan.run(7, 0, N)
         whole = plan.read(clear=True)
         cuts = [0, 1, 4097, N // 3, N // 3 + 1_000_003 % N, N]
