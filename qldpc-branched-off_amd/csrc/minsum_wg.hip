@@ -29,6 +29,8 @@ struct WgArgs {
     const uint16_t *ell_col;       // [round_up(rdeg, 8)][m] by row slot
     const uint32_t *ell_var;       // [cdeg][n] by column slot
     const double *prior_s;         // [n] prior by column slot
+    const int32_t *indptr, *indices;   // CSR (rows by original index): the edge-lane check pass reads a row's columns as one coalesced run
+    int edge_lanes;                // QLDPC_FLAG_WG_EDGE_LANES: 16 lanes per check with shuffle reductions (SURVEY 7-6 option B; measured slower)
     int64_t B;
     const int8_t *synd; const double *prior, *alpha;
     double clip;
@@ -257,6 +259,72 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
         for (int it = 0; it <= max_iter; it++) {
             if (A.fixed || !done) {
                 const double alpha = (it < max_iter) ? A.alpha[it] : 0.0;
+                if (!DAMP && A.edge_lanes) {
+                    // SURVEY 7-6 option B, kept as a measured alternative: a check is owned by 16 lanes (lane = edge k, k + 16, k + 32), the row's
+                    // min1 / min2 / first-argmin come from a 4-step shuffle butterfly, sign bits and the parity from ballots.  The reduction
+                    // (value, index) -> smallest value, then smallest index reproduces "first strict minimum" (kernels.py:301-306); min2 is
+                    // the second smallest with multiplicity = min(winner's min2, loser's min1).
+                    const int gl = tid & 15, gid = tid >> 4, ngroups = T >> 4, gsh = (tid & 63) & ~15;
+                    for (int s0 = 0; s0 < m; s0 += ngroups) {                                // uniform trip count: every lane takes part in the ballots
+                        const int s = s0 + gid;
+                        const bool live = s < m;
+                        const int row = live ? A.row_of_slot[s] : 0;
+                        const int deg = live ? (int)A.degr[s] : 0, e0 = live ? A.indptr[row] : 0;
+                        const bool csyn = live ? (bool)(A.synd[b * m + row] & 1) : false;
+                        double p1s = 0.0, p2s = 0.0;
+                        uint32_t ip_lo = 0u, ip_hi = 0u;
+                        int argp = 127;
+                        if (it > 0 && deg > 0) {
+                            const double2 t = SP[s]; const uint2 u = SI[s];
+                            p1s = t.x; p2s = t.y; argp = (int)(u.y >> 24); ip_lo = u.x; ip_hi = u.y & 0x00FFFFFFu;
+                        }
+                        double m1 = INFINITY, m2 = INFINITY;
+                        int k1 = 127;
+                        uint32_t nlo = 0u, nhi = 0u, parbits = 0u;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const int k = 16 * c + gl;
+                            const bool has = k < deg;
+                            bool vneg = false, xneg = false;
+                            if (has) {
+                                const double v = V[A.indices[e0 + k]];
+                                vneg = v < 0.0;                                              // kernels.py:349,356
+                                double x = v;
+                                if (it > 0) {
+                                    const double mag = (k == argp) ? p2s : p1s;              // kernels.py:313
+                                    const uint32_t pwb = (k < 32) ? (ip_lo >> k) : (ip_hi >> (k - 32));
+                                    x = v - flip_sign(mag, pwb << 31);                       // kernels.py:311-314, 325
+                                    if (NANSEL) x = (x != x) ? 0.0 : x;                      // kernels.py:328-329
+                                    x = wmax_s(wmin_s(x, clip), nclip);                      // kernels.py:330-333
+                                }
+                                xneg = ((uint32_t)__double2hiint(x) >> 31) != 0u;
+                                const double a = fabs(x);
+                                if (a < m1) { m2 = m1; m1 = a; k1 = k; } else if (a < m2) { m2 = a; }   // kernels.py:301-306 on this lane's edges
+                            }
+                            const uint32_t gv = (uint32_t)(__ballot(has && vneg) >> gsh) & 0xFFFFu, gx = (uint32_t)(__ballot(has && xneg) >> gsh) & 0xFFFFu;
+                            parbits ^= gv;
+                            if (c < 2) nlo |= gx << (16 * c); else nhi |= gx;
+                        }
+#pragma unroll
+                        for (int off = 8; off > 0; off >>= 1) {
+                            const double om1 = __shfl_xor(m1, off, 16), om2 = __shfl_xor(m2, off, 16);
+                            const int ok1 = __shfl_xor(k1, off, 16);
+                            const bool take = (om1 < m1) || (om1 == m1 && ok1 < k1);
+                            const double lose1 = take ? m1 : om1, win2 = take ? om2 : m2;
+                            m1 = take ? om1 : m1; k1 = take ? ok1 : k1;
+                            m2 = wmin(win2, lose1);
+                        }
+                        if (gl == 0 && live) {
+                            const bool par = csyn ^ (bool)(__popc(parbits) & 1);
+                            if (it >= 1 && !done && par) unsat[it & 1] = 1;                  // kernels.py:357-359
+                            if (it < max_iter && deg > 0) {                                  // kernels.py:285-286
+                                const uint32_t sp = ((uint32_t)csyn ^ (uint32_t)(__popc(nlo) + __popc(nhi))) << 31;
+                                SP[s] = make_double2(flip_sign(alpha * m1, sp), flip_sign(alpha * m2, sp));
+                                SI[s] = make_uint2(nlo, nhi | ((uint32_t)k1 << 24));
+                            }
+                        }
+                    }
+                } else
                 for (int i = tid; i < m; i += T) {                                           // i = row slot
                     const int deg = (i == tid) ? deg_own : (int)A.degr[i];
                     const bool csyn = (i == tid) ? csyn_own : (bool)(A.synd[b * m + A.row_of_slot[i]] & 1);
@@ -387,6 +455,8 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     A.degc = natural ? g->d_deg_of_col : g->d_deg_of_cslot;
     A.ell_col = natural ? g->d_ell_col : g->d_ell_col_s;
     A.ell_var = natural ? g->d_ell_var : g->d_ell_var_s;
+    A.indptr = g->d_indptr; A.indices = g->d_indices;
+    A.edge_lanes = ((flags & QLDPC_FLAG_WG_EDGE_LANES) && g->max_row_deg <= 48) ? 1 : 0;
     A.B = B; A.synd = d_synd; A.prior = d_prior; A.alpha = d_alpha; A.clip = clip;
     A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;
     const bool vg = (wg_mode(g, damping, flags) == 2), damp = (damping != 1.0);
