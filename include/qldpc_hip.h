@@ -57,6 +57,8 @@ extern "C" {
 /* kernel-variant selectors (parity tests and measurements; results are identical whichever is chosen) */
 #define QLDPC_FLAG_WG_EDGE_LANES 0x2     /* workgroup-per-shot decoder: check pass with 16 lanes per check and shuffle reductions (SURVEY 7-6
                                            option B; measured slower than thread-per-check, profiles/r02_bp_lane_mapping.txt) */
+#define QLDPC_FLAG_OSD_PIPED 0x4         /* OSD-0: pivot resolution of block i+1 overlapped with the row updates of block i (512 <= m <= 1024;
+                                           measured slower than the default, profiles/r02_osd_experiments.txt) */
 #define QLDPC_FLAG_WG_VGLOBAL 0x100     /* workgroup-per-shot decoder: posteriors in HBM/L2 even when they fit LDS (the large-graph form) */
 #define QLDPC_FLAG_WG_GENERIC 0x200     /* workgroup-per-shot decoder: the any-input kernel even for host-verified clean inputs */
 #define QLDPC_FLAG_OSD_UG 0x400         /* OSD-0: row transform in HBM/L2 even when it fits LDS (the m > 1024 form) */

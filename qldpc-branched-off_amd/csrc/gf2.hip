@@ -964,6 +964,21 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     clk_end(P.clk, clk0);
 }
 
+// ELL view of the columns for the OSD kernels: [n][max(max_col_deg, 1)] rows of every column in ascending order, padded with m (the
+// all-zero row of the transform).  Built once per graph on first use (callers hold g->mu).
+int ensure_col_rows(const qldpc_graph *g) {
+    if (g->d_col_rows) return QLDPC_OK;
+    const int cdeg = std::max(g->max_col_deg, 1);
+    std::vector<uint16_t> cr((size_t)std::max(g->n, 1) * cdeg, (uint16_t)g->m);
+    for (int j = 0; j < g->n; j++)
+        for (int k = g->colptr[j]; k < g->colptr[j + 1]; k++) cr[(size_t)j * cdeg + (k - g->colptr[j])] = (uint16_t)g->rowidx[k];
+    QLDPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_col_rows), cr.size() * 2 + 16));
+    QLDPC_HIP_TRY(hipMemcpy(g->d_col_rows, cr.data(), cr.size() * 2, hipMemcpyHostToDevice));
+    return QLDPC_OK;
+}
+
+int osd0_pipe_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+                     const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
 int osd0_fwd_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
                     const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
 
@@ -1020,6 +1035,10 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     if ((flags & QLDPC_FLAG_OSD_FWD) && !(flags & (QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // the forward-elimination kernel (m <= 1024)
         const int rcf = osd0_fwd_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
         if (rcf != QLDPC_OK || handled) return rcf;
+    }
+    if ((flags & QLDPC_FLAG_OSD_PIPED) && !(flags & (QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {   // 512 <= m <= 1024
+        const int rcp = osd0_pipe_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
+        if (rcp != QLDPC_OK || handled) return rcp;
     }
     const int mode = (flags & QLDPC_FLAG_OSD_GLOBAL) ? 0 : plan_osd_lds(g, P, lds, flags);
     if (mode == 0) return QLDPC_OK;

@@ -26,7 +26,7 @@
 // Results are identical to the reference's on every input (also for syndromes outside the column space); the tests compare solutions
 // with a literal Gauss-Jordan on the CPU and with the reference's own outputs.
 //
-// STATUS (round 2, measured on 1 x MI355X, profiles/r02_osd_fwd_experiment.txt): correct, but NOT faster than the round-1 Gauss-Jordan
+// STATUS (round 2, measured on 1 x MI355X, profiles/r02_osd_experiments.txt): correct, but NOT faster than the round-1 Gauss-Jordan
 // kernel on the circuit-level matrices (4.3 M vs 3.5 M cycles per shot), so it is selected only by QLDPC_FLAG_OSD_FWD.  Phase 3 here is
 // cheaper (1.0 M vs 1.29 M cycles per shot) but phase 2 is not: a lone wave issues one instruction per four cycles and every
 // VALU -> SALU -> VALU hop of the pivot chain costs more, 1.4 k cycles per pivot in every formulation tried (all 16 words per step; only
@@ -538,6 +538,7 @@ __global__ __launch_bounds__(1024) void osd0_fwd_kernel(OsdFwdArgs P) {
 }
 
 int host_gf2_rank(const qldpc_graph *g);
+int ensure_col_rows(const qldpc_graph *g);
 
 // false: this kernel does not take the graph (m > 1024 or the state does not fit one CU's LDS) -- the caller falls back
 static bool plan_osd_fwd(const qldpc_graph *g, OsdFwdArgs &P, size_t &lds) {
@@ -573,13 +574,7 @@ int osd0_fwd_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     P.ordws = g->ws_misc.as<uint16_t>();
     P.maskg = reinterpret_cast<uint32_t *>(g->ws_misc.as<unsigned char>() + sz_ord);
     QLDPC_HIP_TRY(hipMemsetAsync(P.maskg, 0, sz_mask, stream));          // words beyond the row length are never written: they must read as zero
-    if (!g->d_col_rows) {                                         // ELL view of the columns (callers hold g->mu), built once per graph
-        std::vector<uint16_t> cr((size_t)g->n * P.cdeg, (uint16_t)g->m);
-        for (int j = 0; j < g->n; j++)
-            for (int k = g->colptr[j]; k < g->colptr[j + 1]; k++) cr[(size_t)j * P.cdeg + (k - g->colptr[j])] = (uint16_t)g->rowidx[k];
-        QLDPC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_col_rows), cr.size() * 2 + 16));
-        QLDPC_HIP_TRY(hipMemcpy(g->d_col_rows, cr.data(), cr.size() * 2, hipMemcpyHostToDevice));
-    }
+    if ((rc = ensure_col_rows(g)) != QLDPC_OK) return rc;
     P.colrows_g = g->d_col_rows;
     P.indptr = g->d_indptr; P.indices = g->d_indices; P.colptr = g->d_colptr; P.rowidx = g->d_rowidx;
     P.list = d_list; P.count = d_count; P.synd = d_synd; P.llr = d_llr; P.hard = d_hard; P.ordering = d_ordering; P.solution = d_solution;

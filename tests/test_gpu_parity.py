@@ -120,7 +120,7 @@ def test_circuit_level_golden(L, golden, oracle, tag):
             assert np.array_equal(sol2, ref2)
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
             # the general global-memory OSD kernel (used when m > 1024) must agree with the LDS-resident one
-            for kfl in (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD):           # ... and so must the forward-elimination kernel
+            for kfl in (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED):   # ... and so must the forward-elimination and the pipelined kernels
                 sol3 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, flags=kfl)
                 sol4 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0,
                                            ordering=g[f"{s}_osd_ordering"][t], flags=kfl)
@@ -916,7 +916,7 @@ def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
         llr = rng.normal(1.0, 3.0, (B, n)); llr[0, : n // 3] = 1.25; llr[1] = np.round(llr[1])     # ties
         hard = (rng.random((B, n)) < 0.1).astype(np.int8)
         want = np.stack([oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)])
-        for env in (0, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD, L.FLAG_OSD_UG, L.FLAG_OSD_NOKILL):
+        for env in (0, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_NOKILL):
             sol = L.osd0_batch(graph, synd, llr, hard, flags=env)
             assert np.array_equal(sol, want), (gi, env, np.flatnonzero((sol != want).any(1)))
 
