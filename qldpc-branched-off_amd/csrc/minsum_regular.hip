@@ -106,6 +106,7 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
     const double clip = A.clip, nclip = -A.clip, damping = A.damping, one_minus_d = 1.0 - A.damping;
     for (int k = threadIdx.x; k < max_iter; k += blockDim.x) reinterpret_cast<double *>(lds + A.offA)[k] = A.alpha[k];
     if (MC && threadIdx.x < 6) Tl[threadIdx.x] = 0ull;
+    const double prior0 = (MC && A.n > 0) ? A.prior[0] : 0.0;                                // Monte-Carlo plans: the uniform prior
     unsigned long long *clkbuf = MC ? A.cold->clk : nullptr;
     const ClkStamp clk0 = clk_begin(clkbuf);
 
@@ -181,12 +182,38 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
 
         for (int it = 0; it <= max_iter; it++) {
             // ======== check phase: syndrome test of values_{it-1}, then R_it from Q_{it-1} ========
-            if ((FIXED ? valid : !done) && has_check) {
-                double x[CDEG];
+            const bool in_check = (FIXED ? valid : !done) && has_check;
+            double x[CDEG];
+            if (in_check) {
                 bool par = csyn;
 #pragma unroll
                 for (int k = 0; k < CDEG; k++) { x[k] = Vl[coff[k]]; par ^= (x[k] < 0.0); }   // kernels.py:349,356
                 if (it >= 1 && !done && par) unsat[it & 1] = 1;                               // kernels.py:357-359
+            }
+            // Reference semantics, iteration 1: at BASELINE's error rates ~97 % of the shots pass the syndrome test of values_0 here, and the
+            // messages of iteration 1 computed alongside the test (the fused form below) are thrown away for them -- a quarter of all the
+            // instructions a shot costs (PMC: 372 VALU wave-instructions per shot, profiles/r02a_pmc.txt).  One extra barrier at it == 1 lets
+            // a team see its verdict first and skip them; later iterations keep the fused form (a team still running there is rarely done).
+            bool skip_msg = false;
+            if (!FIXED && it == 1) {
+                __syncthreads();
+                skip_msg = (unsat[1] == 0);
+            }
+            if (MC && NANFREE && !DAMP && it == 0) {
+                // Monte-Carlo plans decode against a UNIFORM prior p0 (code capacity, alpha.py:119-120), so iteration 0 is a closed form: every
+                // variable-to-check message is p0 (kernels.py:263-265, unclipped), hence min1 = min2 = |p0| and the sign of an edge's
+                // message is the syndrome sign times the signs of the other CDEG - 1 inputs: msg = +-(alpha_0 * |p0|), the same single
+                // rounding as the general form below.  Saves the gather, the min network and the selects: ~60 of the ~290 instructions a
+                // converging shot costs under reference semantics.
+                if (in_check && max_iter > 0) {
+                    const double p0 = prior0;
+                    const bool sneg = csyn != ((((CDEG - 1) & 1) != 0) && (p0 < 0.0));
+                    const double mag = Al[0] * fabs(p0);
+                    const double msg = sneg ? -mag : mag;
+#pragma unroll
+                    for (int k = 0; k < CDEG; k++) { Rprev[k] = msg; Rl[roff + k] = msg; }
+                }
+            } else if (in_check && !skip_msg) {
                 if (it < max_iter) {
                     const double alpha = Al[it];
                     if (it > 0) {
