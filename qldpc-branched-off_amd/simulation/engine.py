@@ -43,7 +43,7 @@ def _estimation_trials(requested, n_cols, error_rate):
 def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, maxIter=50, osd_order=0, use_dynamic_alpha=True,
                    alpha_mode=None, alvarado_alpha=None, alpha_estimation_trials=5000, alpha_estimation_bins=50, precomputed_matrices=None,
                    num_workers=None, base_seed=None, use_jit=True, target_logical_errors=None, max_trials=None, scopt=False,
-                   estimation_plot_dir=None, batch=16384, device=None, **bb_params):
+                   estimation_plot_dir=None, batch=16384, device=None, flags=0, **bb_params):
     if osd_order < 0:
         raise ValueError("osd_order must be >= 0")
     device = parallel.local_device(device)        # explicit argument, else LOCAL_RANK of a torchrun launch, else 0
@@ -117,7 +117,7 @@ def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, m
         extra.update(beta_z=betas[0][0], beta_x=betas[1][0], beta_r2_z=betas[0][1], beta_r2_x=betas[1][1])   # engine.py:482-486
 
     plan = _lib.CircuitPlan(compiled, Lx, Lz, graphs[0], graphs[1], llrs_z, llrs_x, masks[0], masks[1], error_rate, max_iter=maxIter,
-                            alpha_z=alpha_z, alpha_x=alpha_x, alpha_mode=alpha_mode, use_osd=True, batch=batch)
+                            alpha_z=alpha_z, alpha_x=alpha_x, alpha_mode=alpha_mode, use_osd=True, batch=batch, flags=flags)      # flags: QLDPC_FLAG_* kernel variants (extension)
     T = _lib.TALLY
 
     def osdw_batch(begin, count):
