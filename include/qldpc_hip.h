@@ -59,6 +59,10 @@ extern "C" {
                                            option B; measured slower than thread-per-check, profiles/r02_bp_lane_mapping.txt) */
 #define QLDPC_FLAG_OSD_PIPED 0x4         /* OSD-0: pivot resolution of block i+1 overlapped with the row updates of block i (512 <= m <= 1024;
                                            measured slower than the default, profiles/r02_osd_experiments.txt) */
+#define QLDPC_FLAG_OSD_P2WAVES 0x8       /* OSD-0 LDS kernel: pivots of a block resolved by four waves with a barrier per pivot (the round-1 form)
+                                           instead of one wave on registers */
+#define QLDPC_FLAG_OSD_P3SERIAL 0x10000  /* OSD-0 LDS kernel: row updates test one operation after the other (the round-1 form) instead of reading
+                                           a block's tested bits at once */
 #define QLDPC_FLAG_WG_VGLOBAL 0x100     /* workgroup-per-shot decoder: posteriors in HBM/L2 even when they fit LDS (the large-graph form) */
 #define QLDPC_FLAG_WG_GENERIC 0x200     /* workgroup-per-shot decoder: the any-input kernel even for host-verified clean inputs */
 #define QLDPC_FLAG_OSD_UG 0x400         /* OSD-0: row transform in HBM/L2 even when it fits LDS (the m > 1024 form) */

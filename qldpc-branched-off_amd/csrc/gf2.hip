@@ -657,7 +657,7 @@ QLDPC_EXPORT int qldpc_osdw_batch(const qldpc_graph *g, int64_t B, const int8_t 
 namespace qldpc {
 
 struct OsdLdsArgs {
-    int m, n, mw, rankH, K, cdeg, npad, nokill;
+    int m, n, mw, rankH, K, cdeg, npad, nokill, p2waves, p3serial;
     const int32_t *indptr, *indices, *colptr, *rowidx;
     const int32_t *list, *count;
     const int8_t *synd; const double *llr; const int8_t *hard; const int32_t *ordering;
@@ -679,7 +679,70 @@ static_assert(kOsdBlock <= 16, "one wave per column, at most 4 columns per wave 
 __device__ __forceinline__ unsigned long long r_mask_word(const unsigned long long *R, int t, int mw, int w) { return R[t * mw + w]; }
 
 // U is stored row-major with an XOR swizzle of the word index when rows are 16 words (128 B): conflict-free row-parallel updates
-__device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ (q & 15)) : w); }
+// (rows of 16 words belong to threads as q = 16 * lane + wave, see phase 3: the swizzle follows the lane)
+__device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ ((q >> 4) & 15)) : w); }
+
+// ---- phase 2 of the LDS kernel in ONE wave, registers only (rows of <= 16 words) ----
+// lane = 4 * w + g holds word w of the four columns t = 4 i + g (i = 0..3) of the block.  A pivot step is: one ballot over all 16 words
+// of column t (first live set bit, kernels.py:71-75), two lane reads, the column turned into the elimination mask, the mask handed to
+// the other three lanes of every quad by a DPP quad broadcast, and for each register that still holds later columns two ballots (bits
+// a and pp of those columns), the swap (kernels.py:79-82) and the XOR (kernels.py:88-92) -- no LDS access and no barrier inside the
+// chain; the step index is a template parameter so every register index and DPP pattern is static.
+struct QuadPivot {
+    unsigned long long X[4];       // the lane's word of columns g, 4 + g, 8 + g, 12 + g
+    unsigned long long live;       // positions >= lrow within the lane's word
+    int lrow, nops;
+    uint32_t depmask;              // columns found dependent
+    int oppv, optv;                // lane k: pivot position / column index of operation k
+    bool stop;
+    unsigned nzw;                  // diagnostic build: non-zero words over the masks
+};
+
+template <int G>
+__device__ __forceinline__ unsigned long long quad_bcast(unsigned long long x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, G * 0x55, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), G * 0x55, 0xF, 0xF, false);
+    return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ unsigned long long sext64(int f) { return ((unsigned long long)(uint32_t)f << 32) | (uint32_t)f; }
+
+template <int T>
+__device__ __forceinline__ void quad_pivot_step(QuadPivot &S, unsigned long long *R, int mw, int lane, int rankH, int m) {
+    constexpr int IT = T >> 2, GT = T & 3;
+    const int g = lane & 3, w = lane >> 2;
+    const unsigned long long owners = 0x1111111111111111ull << GT;
+    const unsigned long long mword = S.X[IT] & S.live;
+    const unsigned long long bal = __ballot(mword != 0ull) & owners;
+    if (bal == 0ull) { S.depmask |= 1u << T; return; }                                      // dependent on the pivots so far
+    const int src = __builtin_ctzll(bal);
+    const unsigned long long pword = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), src) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, src);
+    const int wp = src >> 2, pb = __builtin_ctzll(pword), pp = wp * 64 + pb, a = S.lrow, wa = a >> 6;
+    const unsigned long long al = (w == wa) ? (1ull << (a & 63)) : 0ull, pl = (w == wp) ? (1ull << pb) : 0ull;
+    // the pivot column becomes the elimination mask: bits a <-> pp swapped (bit pp is 1), then bit a cleared
+    const bool olda = (__ballot((S.X[IT] & al) != 0ull) & owners) != 0ull;
+    unsigned long long rm = olda ? (S.X[IT] | pl) : (S.X[IT] & ~pl);
+    rm &= ~al;                                                                               // (in this order: a == pp must end with bit a clear)
+    if (g == GT && w < mw) R[T * mw + w] = rm;
+#ifdef QLDPC_OSD_TIMERS
+    S.nzw += (unsigned)__builtin_popcountll(__ballot(rm != 0ull) & owners);
+#endif
+    const unsigned long long rmq = quad_bcast<GT>(rm), sw = al | pl;
+#pragma unroll
+    for (int i = IT; i < 4; i++) {
+        if (4 * i + 3 <= T) continue;                                                        // no later column in this register
+        const unsigned long long x = S.X[i];
+        const uint32_t na = (uint32_t)(__ballot((x & al) != 0ull) >> (4 * wa)), np = (uint32_t)(__ballot((x & pl) != 0ull) >> (4 * wp));
+        int fa = __builtin_amdgcn_sbfe((int)na, g, 1), fp = __builtin_amdgcn_sbfe((int)np, g, 1);          // 0 / -1: bit a, bit pp of the lane's column
+        if (i == IT) { const int later = (g > GT) ? -1 : 0; fa &= later; fp &= later; }      // columns <= t of this register are finished
+        S.X[i] = x ^ (sext64(fa ^ fp) & sw) ^ (sext64(fp) & rmq);                            // swap, then add the pivot row where bit a is set
+    }
+    S.live &= ~al;
+    S.oppv = (lane == S.nops) ? pp : S.oppv;
+    S.optv = (lane == S.nops) ? T : S.optv;
+    S.nops++; S.lrow++;
+    if (S.lrow >= rankH || S.lrow >= m) S.stop = true;                                       // full rank: the remaining columns cannot pivot
+}
 
 // Position-space formulation.  T (current rows = T * original rows, rows in their CURRENT physical order, i.e. after the
 // reference's swaps kernels.py:79-82) is kept as U = T^T: U[q] bit p = T[p][q].  Rows 0..m-1 of U belong to the original
@@ -708,6 +771,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     const int total = *P.count;
     const ClkStamp clk0 = clk_begin(P.clk);
     int *s_item = reinterpret_cast<int *>(stp + kOsdBlock);                  // the list entry this workgroup processes next
+    int *opm = s_item + 4, *opx = opm + kOsdBlock;                           // per operation: how it changes the bits later operations of the block test
     for (;;) {
         if (tid == 0) *s_item = atomicAdd(P.queue, 1);
         __syncthreads();
@@ -745,7 +809,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         }
         __syncthreads();
         int row = 0;
-        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0;
+        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0, d_nzw = 0, d_wops = 0, d_lops = 0, c_p3own = 0;
         const long long t_sorted = OSD_CLOCK();
         bool finished = (P.rankH == 0);
         for (int base = 0; base < n && !finished; base += K) {
@@ -841,7 +905,57 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 // (1.7 M cycles per shot), one wave per column (1.85 M), four columns resolved inside a wave per barrier (1.75 M);
                 // this form: 1.36 M -- the cost is the dependent ballot -> scalar -> lane-read chain of a step, not the barrier.
                 int nops = 0, anydep = 0;
-                {
+                if (!UG && !P.p2waves) {
+                    // rows of <= 16 words: the whole block in wave 0, registers only (quad_pivot_step above); the other waves wait at the barrier
+                    if (tid < 64) {
+                        const int lane = tid, g = lane & 3, w = lane >> 2, wq = row >> 6;
+                        QuadPivot S;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) S.X[i] = (4 * i + g < nb && w < mw) ? R[(4 * i + g) * mw + w] : 0ull;
+                        S.live = (w > wq) ? ~0ull : ((w == wq) ? (~0ull << (row & 63)) : 0ull);
+                        S.lrow = row; S.nops = 0; S.depmask = 0u; S.oppv = 0; S.optv = 0; S.stop = false; S.nzw = 0u;
+#define QLDPC_QSTEP(TT) if (TT < nb && !S.stop) quad_pivot_step<TT>(S, R, mw, lane, P.rankH, m);
+                        QLDPC_QSTEP(0) QLDPC_QSTEP(1) QLDPC_QSTEP(2) QLDPC_QSTEP(3) QLDPC_QSTEP(4) QLDPC_QSTEP(5) QLDPC_QSTEP(6) QLDPC_QSTEP(7)
+                        QLDPC_QSTEP(8) QLDPC_QSTEP(9) QLDPC_QSTEP(10) QLDPC_QSTEP(11) QLDPC_QSTEP(12) QLDPC_QSTEP(13) QLDPC_QSTEP(14) QLDPC_QSTEP(15)
+#undef QLDPC_QSTEP
+                        if (lane < S.nops) { opa[lane] = row + lane; opp[lane] = S.oppv; opt[lane] = S.optv; pvcol[row + lane] = sidx[bcol[S.optv]]; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        {   // what operation k does to the bits operation j > k will test (positions a_j = row + j and pp_j) in a row it changes:
+                            // opm[k]: bit j = mask_k[a_j], bit 16 + j = mask_k[pp_j] (the XOR); opx[k]: bit j = (a_j == pp_k), bit 16 + j = (pp_j == pp_k)
+                            // (the swap puts the row's old bit a_k at position pp_k).  Lane 4 k + jq looks at j = 4 jq .. 4 jq + 3.
+                            const int k = lane >> 2, jq = lane & 3;
+                            uint32_t v1 = 0u, v2 = 0u;
+                            if (k < S.nops) {
+                                const int ppk = opp[k];
+                                const unsigned long long *mkk = R + opt[k] * mw;
+#pragma unroll
+                                for (int jj = 0; jj < 4; jj++) {
+                                    const int j = 4 * jq + jj;
+                                    if (j > k && j < S.nops) {
+                                        const int aj = row + j, pj = opp[j];
+                                        v1 |= (uint32_t)((mkk[aj >> 6] >> (aj & 63)) & 1ull) << j;
+                                        v1 |= (uint32_t)((mkk[pj >> 6] >> (pj & 63)) & 1ull) << (16 + j);
+                                        v2 |= (uint32_t)(aj == ppk) << j;
+                                        v2 |= (uint32_t)(pj == ppk) << (16 + j);
+                                    }
+                                }
+                            }
+                            v1 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v1, 0xB1, 0xF, 0xF, true);
+                            v1 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v1, 0x4E, 0xF, 0xF, true);
+                            v2 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v2, 0xB1, 0xF, 0xF, true);
+                            v2 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v2, 0x4E, 0xF, 0xF, true);
+                            if (jq == 0 && k < S.nops) { opm[k] = (int)v1; opx[k] = (int)v2; }
+                        }
+                        if (lane < nb && ((S.depmask >> lane) & 1u)) alive[bcol[lane]] = 0;
+                        if (lane == 0) { blk[1] = S.nops; blk[2] = (S.depmask != 0u) ? 1 : 0; }
+#ifdef QLDPC_OSD_TIMERS
+                        d_nzw += S.nzw;
+#endif
+                    }
+                    __syncthreads();
+                    nops = blk[1]; anydep = blk[2];
+                } else {
                     // lanes per column: 16 / 32 / 64 for rows of <= 16 / 32 / 64 words; columns per wave 4 / 2 / 1; holder waves 4 / 8 / 16
                     const int lsh = (mw <= 16) ? 4 : ((mw <= 32) ? 5 : 6), LPC = 1 << lsh, cpw = 64 >> lsh, osh = 6 - lsh;
                     const unsigned long long gmask = (LPC == 64) ? ~0ull : ((1ull << LPC) - 1ull);
@@ -892,45 +1006,122 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                         nops++; lrow++;
                         if (lrow >= P.rankH || lrow >= m) break;                                 // full rank: the remaining columns cannot pivot
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
                 c_p2 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
                 // ---- phase 3: apply the block's operations to every row of U (and to b) ----
-                for (int q = tid; q < m + 2; q += T) {
-                    if (q == m) continue;
-                    for (int k = 0; k < nops; k++) {
-                        const int a = __builtin_amdgcn_readfirstlane(opa[k]), pp = __builtin_amdgcn_readfirstlane(opp[k]), wa = a >> 6, wp = pp >> 6;
-                        const unsigned long long *mk = R + __builtin_amdgcn_readfirstlane(opt[k]) * mw;
-                        const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
-                        unsigned long long xa = U[uswz(q, wa, mw)];
-                        const unsigned long long xp = (wp == wa) ? xa : U[uswz(q, wp, mw)];
-                        const bool ba = (xa & abit) != 0ull, bp = (xp & pbit) != 0ull;
-                        if (ba != bp) {
-                            if (wp == wa) { U[uswz(q, wa, mw)] = xa ^ abit ^ pbit; }
-                            else { U[uswz(q, wa, mw)] = xa ^ abit; U[uswz(q, wp, mw)] = xp ^ pbit; }
+                // rows of 16 words go to threads as q = 16 * lane + wave: the rows an operation changes cluster (the rows near the pivot
+                // position change under every operation of the block), consecutive rows in one wave made that wave the critical path
+                const bool strided = (mw == 16);                             // (mw == 16 implies 1024 threads)
+                auto rowq = [&](int qb) { return strided ? qb + ((tid & 63) << 4) + (tid >> 6) : qb + tid; };
+                // the two halves of an operation (kernels.py:79-92) on row q: swap bits a <-> pp; add the elimination mask
+                auto swap_bits = [&](int q, int a, int pp) {
+                    const int wa = a >> 6, wp = pp >> 6;
+                    const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
+                    if (wp == wa) { U[uswz(q, wa, mw)] ^= abit ^ pbit; }
+                    else { const unsigned long long xa = U[uswz(q, wa, mw)], xp = U[uswz(q, wp, mw)]; U[uswz(q, wa, mw)] = xa ^ abit; U[uswz(q, wp, mw)] = xp ^ pbit; }
+                };
+                auto add_mask = [&](int q, const unsigned long long *mk) {
+                    if (mw == 16) {                                          // all 32 reads in flight before the first XOR (a rolled loop waits per word)
+                        unsigned long long u[16];
+#pragma unroll
+                        for (int w = 0; w < 16; w++) u[w] = U[q * 16 + (w ^ ((q >> 4) & 15))];
+#pragma unroll
+                        for (int w = 0; w < 16; w++) u[w] ^= mk[w];
+#pragma unroll
+                        for (int w = 0; w < 16; w++) U[q * 16 + (w ^ ((q >> 4) & 15))] = u[w];
+                    } else {
+                        for (int w0 = 0; w0 < mw; w0 += 8) {                 // 8 words in flight (rows live in HBM/L2 in the UG kernel)
+                            unsigned long long u[8];
+#pragma unroll
+                            for (int j2 = 0; j2 < 8; j2++) u[j2] = (w0 + j2 < mw) ? U[uswz(q, w0 + j2, mw)] : 0ull;
+#pragma unroll
+                            for (int j2 = 0; j2 < 8; j2++) if (w0 + j2 < mw) U[uswz(q, w0 + j2, mw)] = u[j2] ^ mk[w0 + j2];
                         }
-                        if (bp) {                                            // bit a after the swap: add the pivot row (kernels.py:88-92)
-                            if (mw == 16) {                                  // all 32 reads in flight before the first XOR (a rolled loop waits per word)
-                                unsigned long long u[16];
+                    }
+                };
+                if (!UG && !P.p2waves && !P.p3serial && nops > 0) {
+                    // Measured on the circuit-level matrices: 3.5 % of the (row, operation) pairs change the row, so a per-operation
+                    // "read two words, test, branch" is all latency.  Here a row reads the 2 + 16 words holding the positions the WHOLE
+                    // block tests back to back and keeps one bit per operation and kind (ab: bit a_k, pb: bit pp_k); the wave visits only
+                    // the operations some lane has a set bit for; a row that changes updates its later bits from opm / opx (wave 0 made
+                    // them after phase 2) instead of reading again.
+                    int ppv = opp[tid & 15], ptv = opt[tid & 15], pmv = opm[tid & 15], pxv = opx[tid & 15];      // operation k: lane k of every 16
+                    asm volatile("" : "+v"(ppv), "+v"(ptv), "+v"(pmv), "+v"(pxv));
+                    const int ws = row >> 6, sh = row & 63;
+                    const uint32_t valid = (1u << nops) - 1u;
+                    for (int qb = 0; qb < m + 2; qb += T) {
+                        const int q = rowq(qb);
+                        const bool act = (q < m + 2) && (q != m);
+                        const int qq = act ? q : m;                          // idle lanes look at the all-zero row
+                        uint32_t ab, pb = 0u;
+                        {
+                            const unsigned long long A0 = U[uswz(qq, ws, mw)], A1 = (ws + 1 < mw) ? U[uswz(qq, ws + 1, mw)] : 0ull;
+                            unsigned long long Pw[kOsdBlock];
 #pragma unroll
-                                for (int w = 0; w < 16; w++) u[w] = U[q * 16 + (w ^ (q & 15))];
+                            for (int k = 0; k < kOsdBlock; k++) {
+                                const int pk = __builtin_amdgcn_readlane(ppv, k);
+                                Pw[k] = U[uswz(qq, (k < nops) ? (pk >> 6) : 0, mw)];
+                            }
+                            ab = (uint32_t)((A0 >> sh) | (sh ? (A1 << (64 - sh)) : 0ull)) & valid;             // positions row .. row + nops - 1
 #pragma unroll
-                                for (int w = 0; w < 16; w++) u[w] ^= mk[w];
-#pragma unroll
-                                for (int w = 0; w < 16; w++) U[q * 16 + (w ^ (q & 15))] = u[w];
-                            } else {
-                                for (int w0 = 0; w0 < mw; w0 += 8) {         // 8 words in flight (rows live in HBM/L2 in the UG kernel)
-                                    unsigned long long u[8];
-#pragma unroll
-                                    for (int j2 = 0; j2 < 8; j2++) u[j2] = (w0 + j2 < mw) ? U[uswz(q, w0 + j2, mw)] : 0ull;
-#pragma unroll
-                                    for (int j2 = 0; j2 < 8; j2++) if (w0 + j2 < mw) U[uswz(q, w0 + j2, mw)] = u[j2] ^ mk[w0 + j2];
-                                }
+                            for (int k = 0; k < kOsdBlock; k++) {
+                                const int pk = __builtin_amdgcn_readlane(ppv, k);
+                                pb |= (uint32_t)((Pw[k] >> (pk & 63)) & 1ull) << k;
+                            }
+                            pb &= valid;
+                        }
+                        int kdone = -1;
+                        for (;;) {
+                            uint32_t x = ab | pb;                            // OR over the wave
+                            x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+                            x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+                            x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);      // row_half_mirror
+                            x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);      // row_mirror
+                            uint32_t wtb = (uint32_t)__builtin_amdgcn_readlane((int)x, 0) | (uint32_t)__builtin_amdgcn_readlane((int)x, 16) |
+                                           (uint32_t)__builtin_amdgcn_readlane((int)x, 32) | (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+                            if (kdone >= 0) wtb &= ~1u << kdone;
+                            if (wtb == 0u) break;
+                            const int k = __builtin_ctz(wtb);
+                            kdone = k;
+                            const bool ba = (ab >> k) & 1u, bp = (pb >> k) & 1u;
+#ifdef QLDPC_OSD_TIMERS
+                            { d_wops++; d_lops += __builtin_popcountll(__ballot(ba || bp)); }
+#endif
+                            if (ba != bp) {                                  // the swap leaves the row's old bit a at position pp
+                                swap_bits(q, row + k, __builtin_amdgcn_readlane(ppv, k));
+                                const uint32_t xx = (uint32_t)__builtin_amdgcn_readlane(pxv, k), sa = xx & 0xFFFFu, sp = xx >> 16;
+                                ab = ba ? (ab | sa) : (ab & ~sa);
+                                pb = ba ? (pb | sp) : (pb & ~sp);
+                            }
+                            if (bp) {                                        // bit a after the swap: add the pivot row (kernels.py:88-92)
+                                add_mask(q, R + __builtin_amdgcn_readlane(ptv, k) * mw);
+                                const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane(pmv, k);
+                                ab ^= mm & 0xFFFFu;
+                                pb ^= mm >> 16;
                             }
                         }
                     }
+                } else
+                for (int qb = 0; qb < m + 2; qb += T) {
+                    const int q = rowq(qb);
+                    if (q >= m + 2 || q == m) continue;
+                    for (int k = 0; k < nops; k++) {
+                        const int a = __builtin_amdgcn_readfirstlane(opa[k]), pp = __builtin_amdgcn_readfirstlane(opp[k]), wa = a >> 6, wp = pp >> 6;
+                        const unsigned long long xa = U[uswz(q, wa, mw)];
+                        const unsigned long long xp = (wp == wa) ? xa : U[uswz(q, wp, mw)];
+                        const bool ba = ((xa >> (a & 63)) & 1ull) != 0ull, bp = ((xp >> (pp & 63)) & 1ull) != 0ull;
+#ifdef QLDPC_OSD_TIMERS
+                        { const unsigned long long bb = __ballot(ba || bp); if (bb) { d_wops++; d_lops += __builtin_popcountll(bb); } }
+#endif
+                        if (ba != bp) swap_bits(q, a, pp);
+                        if (bp) add_mask(q, R + __builtin_amdgcn_readfirstlane(opt[k]) * mw);
+                    }
                 }
                 row += nops;
+#ifdef QLDPC_OSD_TIMERS
+                c_p3own += OSD_CLOCK() - tp;
+#endif
                 __syncthreads();
                 c_p3 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
                 if (row >= P.rankH || row >= m) { finished = true; break; }
@@ -948,8 +1139,11 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
             atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)row);
             atomicAdd(&P.dbg[4], (unsigned long long)(OSD_CLOCK() - t_start)); atomicAdd(&P.dbg[5], d_kills); atomicAdd(&P.dbg[6], d_blocks);
             atomicAdd(&P.dbg[8], (unsigned long long)(t_sorted - t_start)); atomicAdd(&P.dbg[9], c_p1); atomicAdd(&P.dbg[10], c_p2); atomicAdd(&P.dbg[11], c_p3);
-            atomicAdd(&P.dbg[12], c_kill);
+            atomicAdd(&P.dbg[12], c_kill); atomicAdd(&P.dbg[7], d_nzw);
         }
+#ifdef QLDPC_OSD_TIMERS
+        if (P.dbg && (tid & 63) == 0) { atomicAdd(&P.dbg[14], d_wops); atomicAdd(&P.dbg[15], d_lops); atomicAdd(&P.dbg[13], c_p3own / (blockDim.x >> 6)); }
+#endif
         // ---- back-fill (osd.py:19-25): e[pivot col] = reduced rhs at the pivot row; solution = (hard + e) % 2 ----
         __syncthreads();
         if (sol != hard) for (int j = tid; j < n; j += T) sol[j] = hard[j];
@@ -1018,7 +1212,7 @@ static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds, int fl
         P.offRows = (int)off; off += (size_t)P.K * P.cdeg * 2;
         P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
         P.offR = (int)off; off += (size_t)kOsdBlock * P.mw * 8;
-        P.offBlk = (int)off; off += (4 + 6 * kOsdBlock + 4) * 4;
+        P.offBlk = (int)off; off += (4 + 6 * kOsdBlock + 4 + 2 * kOsdBlock) * 4;
         P.offMisc = (int)off; off += 64;
         P.offSort = (int)off; off += (mode == 2) ? sort_cnt : 0;
         lds = off + 16;
@@ -1059,6 +1253,8 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     P.clk = g->clk_probe;
     P.dbg = osd_timer_buffer();      // NULL unless built with -DQLDPC_OSD_TIMERS (make timers)
     P.nokill = (flags & QLDPC_FLAG_OSD_NOKILL) ? 1 : 0;
+    P.p2waves = (flags & QLDPC_FLAG_OSD_P2WAVES) ? 1 : 0;
+    P.p3serial = (flags & QLDPC_FLAG_OSD_P3SERIAL) ? 1 : 0;
     const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m + 2, 256), 64));
     if ((rc = g->ws_queue.ensure(16)) != QLDPC_OK) return rc;
     P.queue = g->ws_queue.as<int>() + 2;

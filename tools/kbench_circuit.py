@@ -71,7 +71,7 @@ for rep in range(a.reps):
         if h[0]:
             print(f"  [osd timers] shots={h[0]:.0f} chunks/shot={h[1] / h[0]:.2f} cols/shot={h[2] / h[0]:.1f} pivots/shot={h[3] / h[0]:.1f} kills/shot={h[5] / h[0]:.1f} "
                   f"blocks/shot={h[6] / h[0]:.1f} kcycles/shot={h[4] / h[0] / 1e3:.1f} (sort {h[8] / h[0] / 1e3:.0f} p1 {h[9] / h[0] / 1e3:.0f} p2 {h[10] / h[0] / 1e3:.0f} "
-                  f"p3 {h[11] / h[0] / 1e3:.0f} kill {h[12] / h[0] / 1e3:.0f} backsub {h[13] / h[0] / 1e3:.0f}; p2 serial chain {h[7] / h[0] / 1e3:.0f}, far-pivot blocks/shot {h[14] / h[0]:.1f})", flush=True)
+                  f"p3 {h[11] / h[0] / 1e3:.0f} kill {h[12] / h[0] / 1e3:.0f} backsub {h[13] / h[0] / 1e3:.0f}; extra counters per shot [7] {h[7] / h[0]:.1f} [14] {h[14] / h[0]:.1f} [15] {h[15] / h[0]:.1f})", flush=True)
 
 if a.cpu_trials > 0:
     from oracle import oracle as orc            # CPU checker, timed beside the GPU path (never part of it)
