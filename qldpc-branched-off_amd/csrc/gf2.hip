@@ -679,8 +679,9 @@ static_assert(kOsdBlock <= 16, "one wave per column, at most 4 columns per wave 
 __device__ __forceinline__ unsigned long long r_mask_word(const unsigned long long *R, int t, int mw, int w) { return R[t * mw + w]; }
 
 // U is stored row-major with an XOR swizzle of the word index when rows are 16 words (128 B): conflict-free row-parallel updates
-// (rows of 16 words belong to threads as q = 16 * lane + wave, see phase 3: the swizzle follows the lane)
-__device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ ((q >> 4) & 15)) : w); }
+// (rows of 16 words belong to threads as q = 16 * lane + (wave + lane) % 16, see phase 3: the swizzle follows the lane and moves PAIRS of
+// words, so that a row can also be read and written 16 bytes at a time)
+__device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ ((q >> 3) & 14)) : w); }
 
 // ---- phase 2 of the LDS kernel in ONE wave, registers only (rows of <= 16 words) ----
 // lane = 4 * w + g holds word w of the four columns t = 4 i + g (i = 0..3) of the block.  A pivot step is: one ballot over all 16 words
@@ -771,7 +772,6 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     const int total = *P.count;
     const ClkStamp clk0 = clk_begin(P.clk);
     int *s_item = reinterpret_cast<int *>(stp + kOsdBlock);                  // the list entry this workgroup processes next
-    int *opm = s_item + 4, *opx = opm + kOsdBlock;                           // per operation: how it changes the bits later operations of the block test
     for (;;) {
         if (tid == 0) *s_item = atomicAdd(P.queue, 1);
         __syncthreads();
@@ -919,34 +919,6 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                         QLDPC_QSTEP(8) QLDPC_QSTEP(9) QLDPC_QSTEP(10) QLDPC_QSTEP(11) QLDPC_QSTEP(12) QLDPC_QSTEP(13) QLDPC_QSTEP(14) QLDPC_QSTEP(15)
 #undef QLDPC_QSTEP
                         if (lane < S.nops) { opa[lane] = row + lane; opp[lane] = S.oppv; opt[lane] = S.optv; pvcol[row + lane] = sidx[bcol[S.optv]]; }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        {   // what operation k does to the bits operation j > k will test (positions a_j = row + j and pp_j) in a row it changes:
-                            // opm[k]: bit j = mask_k[a_j], bit 16 + j = mask_k[pp_j] (the XOR); opx[k]: bit j = (a_j == pp_k), bit 16 + j = (pp_j == pp_k)
-                            // (the swap puts the row's old bit a_k at position pp_k).  Lane 4 k + jq looks at j = 4 jq .. 4 jq + 3.
-                            const int k = lane >> 2, jq = lane & 3;
-                            uint32_t v1 = 0u, v2 = 0u;
-                            if (k < S.nops) {
-                                const int ppk = opp[k];
-                                const unsigned long long *mkk = R + opt[k] * mw;
-#pragma unroll
-                                for (int jj = 0; jj < 4; jj++) {
-                                    const int j = 4 * jq + jj;
-                                    if (j > k && j < S.nops) {
-                                        const int aj = row + j, pj = opp[j];
-                                        v1 |= (uint32_t)((mkk[aj >> 6] >> (aj & 63)) & 1ull) << j;
-                                        v1 |= (uint32_t)((mkk[pj >> 6] >> (pj & 63)) & 1ull) << (16 + j);
-                                        v2 |= (uint32_t)(aj == ppk) << j;
-                                        v2 |= (uint32_t)(pj == ppk) << (16 + j);
-                                    }
-                                }
-                            }
-                            v1 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v1, 0xB1, 0xF, 0xF, true);
-                            v1 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v1, 0x4E, 0xF, 0xF, true);
-                            v2 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v2, 0xB1, 0xF, 0xF, true);
-                            v2 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v2, 0x4E, 0xF, 0xF, true);
-                            if (jq == 0 && k < S.nops) { opm[k] = (int)v1; opx[k] = (int)v2; }
-                        }
                         if (lane < nb && ((S.depmask >> lane) & 1u)) alive[bcol[lane]] = 0;
                         if (lane == 0) { blk[1] = S.nops; blk[2] = (S.depmask != 0u) ? 1 : 0; }
 #ifdef QLDPC_OSD_TIMERS
@@ -1013,7 +985,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 // rows of 16 words go to threads as q = 16 * lane + wave: the rows an operation changes cluster (the rows near the pivot
                 // position change under every operation of the block), consecutive rows in one wave made that wave the critical path
                 const bool strided = (mw == 16);                             // (mw == 16 implies 1024 threads)
-                auto rowq = [&](int qb) { return strided ? qb + ((tid & 63) << 4) + (tid >> 6) : qb + tid; };
+                auto rowq = [&](int qb) { return strided ? qb + ((tid & 63) << 4) + (((tid >> 6) + tid) & 15) : qb + tid; };
                 // the two halves of an operation (kernels.py:79-92) on row q: swap bits a <-> pp; add the elimination mask
                 auto swap_bits = [&](int q, int a, int pp) {
                     const int wa = a >> 6, wp = pp >> 6;
@@ -1022,14 +994,19 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     else { const unsigned long long xa = U[uswz(q, wa, mw)], xp = U[uswz(q, wp, mw)]; U[uswz(q, wa, mw)] = xa ^ abit; U[uswz(q, wp, mw)] = xp ^ pbit; }
                 };
                 auto add_mask = [&](int q, const unsigned long long *mk) {
-                    if (mw == 16) {                                          // all 32 reads in flight before the first XOR (a rolled loop waits per word)
-                        unsigned long long u[16];
+                    if (mw == 16) {                                          // all reads in flight before the first XOR (a rolled loop waits per word)
+                        ulonglong2 u[8], k2[8];
+                        ulonglong2 *Uq = reinterpret_cast<ulonglong2 *>(U + q * 16);
+                        const ulonglong2 *mk2 = reinterpret_cast<const ulonglong2 *>(mk);
+                        const int sz = (q >> 4) & 7;                         // uswz() on pairs of words
 #pragma unroll
-                        for (int w = 0; w < 16; w++) u[w] = U[q * 16 + (w ^ ((q >> 4) & 15))];
+                        for (int w = 0; w < 8; w++) u[w] = Uq[w ^ sz];
 #pragma unroll
-                        for (int w = 0; w < 16; w++) u[w] ^= mk[w];
+                        for (int w = 0; w < 8; w++) k2[w] = mk2[w];
 #pragma unroll
-                        for (int w = 0; w < 16; w++) U[q * 16 + (w ^ ((q >> 4) & 15))] = u[w];
+                        for (int w = 0; w < 8; w++) { u[w].x ^= k2[w].x; u[w].y ^= k2[w].y; }
+#pragma unroll
+                        for (int w = 0; w < 8; w++) Uq[w ^ sz] = u[w];
                     } else {
                         for (int w0 = 0; w0 < mw; w0 += 8) {                 // 8 words in flight (rows live in HBM/L2 in the UG kernel)
                             unsigned long long u[8];
@@ -1046,10 +1023,13 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     // block tests back to back and keeps one bit per operation and kind (ab: bit a_k, pb: bit pp_k); the wave visits only
                     // the operations some lane has a set bit for; a row that changes updates its later bits from opm / opx (wave 0 made
                     // them after phase 2) instead of reading again.
-                    int ppv = opp[tid & 15], ptv = opt[tid & 15], pmv = opm[tid & 15], pxv = opx[tid & 15];      // operation k: lane k of every 16
-                    asm volatile("" : "+v"(ppv), "+v"(ptv), "+v"(pmv), "+v"(pxv));
+                    int ppv = opp[tid & 15], ptv = opt[tid & 15];           // operation k's (pp, column) sit in lane k of every 16
+                    asm volatile("" : "+v"(ppv), "+v"(ptv));
                     const int ws = row >> 6, sh = row & 63;
                     const uint32_t valid = (1u << nops) - 1u;
+                    const uint32_t *U32 = reinterpret_cast<const uint32_t *>(U);
+                    // lanes 0-15 of every 32 stand for position a_j = row + j, lanes 16-31 for pp_j (j = lane % 16): see the bit updates below
+                    const int j16 = tid & 15, mypos = (j16 < nops) ? ((tid & 16) ? ppv : row + j16) : 0;
                     for (int qb = 0; qb < m + 2; qb += T) {
                         const int q = rowq(qb);
                         const bool act = (q < m + 2) && (q != m);
@@ -1057,17 +1037,17 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                         uint32_t ab, pb = 0u;
                         {
                             const unsigned long long A0 = U[uswz(qq, ws, mw)], A1 = (ws + 1 < mw) ? U[uswz(qq, ws + 1, mw)] : 0ull;
-                            unsigned long long Pw[kOsdBlock];
+                            uint32_t Pw[kOsdBlock];
 #pragma unroll
                             for (int k = 0; k < kOsdBlock; k++) {
-                                const int pk = __builtin_amdgcn_readlane(ppv, k);
-                                Pw[k] = U[uswz(qq, (k < nops) ? (pk >> 6) : 0, mw)];
+                                const int pk = (k < nops) ? __builtin_amdgcn_readlane(ppv, k) : 0;
+                                Pw[k] = U32[2 * uswz(qq, pk >> 6, mw) + ((pk >> 5) & 1)];
                             }
                             ab = (uint32_t)((A0 >> sh) | (sh ? (A1 << (64 - sh)) : 0ull)) & valid;             // positions row .. row + nops - 1
 #pragma unroll
                             for (int k = 0; k < kOsdBlock; k++) {
                                 const int pk = __builtin_amdgcn_readlane(ppv, k);
-                                pb |= (uint32_t)((Pw[k] >> (pk & 63)) & 1ull) << k;
+                                pb |= ((Pw[k] >> (pk & 31)) & 1u) << k;
                             }
                             pb &= valid;
                         }
@@ -1084,19 +1064,27 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                             if (wtb == 0u) break;
                             const int k = __builtin_ctz(wtb);
                             kdone = k;
+                            const int ppk = __builtin_amdgcn_readlane(ppv, k);
+                            const unsigned long long *mk = R + __builtin_amdgcn_readlane(ptv, k) * mw;
+                            // what operation k does to the bits the later operations j > k test in a row it changes: the swap puts the row's old
+                            // bit a_k at position pp_k (xx: bit j = (a_j == pp_k), bit 16 + j = (pp_j == pp_k)); the XOR flips them by the mask's
+                            // bits at those positions (mm: bit j = mask_k[a_j], bit 16 + j = mask_k[pp_j])
+                            const bool later = (j16 > k) && (j16 < nops);
+                            const uint32_t mword = reinterpret_cast<const uint32_t *>(mk)[2 * (mypos >> 6) + ((mypos >> 5) & 1)];
+                            const uint32_t xx = (uint32_t)__ballot(later && mypos == ppk);
+                            const uint32_t mm = (uint32_t)__ballot(later && ((mword >> (mypos & 31)) & 1u));
                             const bool ba = (ab >> k) & 1u, bp = (pb >> k) & 1u;
 #ifdef QLDPC_OSD_TIMERS
                             { d_wops++; d_lops += __builtin_popcountll(__ballot(ba || bp)); }
 #endif
-                            if (ba != bp) {                                  // the swap leaves the row's old bit a at position pp
-                                swap_bits(q, row + k, __builtin_amdgcn_readlane(ppv, k));
-                                const uint32_t xx = (uint32_t)__builtin_amdgcn_readlane(pxv, k), sa = xx & 0xFFFFu, sp = xx >> 16;
+                            if (ba != bp) {
+                                swap_bits(q, row + k, ppk);
+                                const uint32_t sa = xx & 0xFFFFu, sp = xx >> 16;
                                 ab = ba ? (ab | sa) : (ab & ~sa);
                                 pb = ba ? (pb | sp) : (pb & ~sp);
                             }
                             if (bp) {                                        // bit a after the swap: add the pivot row (kernels.py:88-92)
-                                add_mask(q, R + __builtin_amdgcn_readlane(ptv, k) * mw);
-                                const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane(pmv, k);
+                                add_mask(q, mk);
                                 ab ^= mm & 0xFFFFu;
                                 pb ^= mm >> 16;
                             }
@@ -1212,7 +1200,7 @@ static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds, int fl
         P.offRows = (int)off; off += (size_t)P.K * P.cdeg * 2;
         P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
         P.offR = (int)off; off += (size_t)kOsdBlock * P.mw * 8;
-        P.offBlk = (int)off; off += (4 + 6 * kOsdBlock + 4 + 2 * kOsdBlock) * 4;
+        P.offBlk = (int)off; off += (4 + 6 * kOsdBlock + 4) * 4;
         P.offMisc = (int)off; off += 64;
         P.offSort = (int)off; off += (mode == 2) ? sort_cnt : 0;
         lds = off + 16;
