@@ -447,7 +447,7 @@ static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B,
         std::lock_guard<std::mutex> lk(g->mu);
         g->clk_probe = (clk && sector == 0) ? clk : nullptr;                  // sector Z carries the probe (one writer per buffer)
         rc = minsum_decode_dispatch(g, B, syn.as<int8_t>(), prior.as<double>(), P->max_iter, alpha.as<double>(), P->damping, P->clip,
-                                    (P->flags & 0xFFFF) | (P->nanfree ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0),
+                                    (P->flags & QLDPC_FLAG_PUBLIC_MASK) | (P->nanfree ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0),
                                     P->nanfree, det.as<int8_t>(), llr.as<double>(), conv.as<uint8_t>(), iter.as<int32_t>(), s);
         g->clk_probe = nullptr;
     }

@@ -97,7 +97,7 @@ static int decode_dev_impl(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     if ((rc = g->alpha_table(tab, s, &d_alpha)) != QLDPC_OK) return rc;
     // prior_finite here means "host-verified clean prior" (finite, no -0.0); clip and alphas are checked the same way
     bool nanfree = prior_finite && std::isfinite(damping) && inputs_clean(nullptr, 0, clip_llr, tab.data(), max_iter);
-    flags = (flags & 0xFFFF) | (prior_finite ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0);
+    flags = (flags & QLDPC_FLAG_PUBLIC_MASK) | (prior_finite ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0);
     return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip_llr, flags, nanfree, d_err,
                                   d_llr, d_conv, d_iter, s);
 }

@@ -768,6 +768,9 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     int2 *stp = reinterpret_cast<int2 *>(opt + kOsdBlock);      // (a or -1, pp) published by the owner of column t
     uint16_t *ordw = P.ordws + (size_t)blockIdx.x * n;
     const int brow = m + 1;                                                // U row that carries b
+    // U[q][w]: LDS: row-major, swizzled (uswz); HBM/L2 (UG): WORD-major, w * (m + 2) + q -- a thread owns a row and walks its words, so the
+    // lanes of a wave-load then touch neighbouring addresses instead of 64 different cache lines (the row-major form was address-rate bound)
+    auto uix = [&](int q, int w) -> int { return UG ? w * (m + 2) + q : uswz(q, w, mw); };
 
     const int total = *P.count;
     const ClkStamp clk0 = clk_begin(P.clk);
@@ -802,14 +805,15 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         for (int t = tid; t < (m + 2) * mw; t += T) U[t] = 0ull;
         __syncthreads();
         for (int r = tid; r < m; r += T) {
-            U[uswz(r, r >> 6, mw)] = 1ull << (r & 63);
+            U[uix(r, r >> 6)] = 1ull << (r & 63);
             int sy = synd[r] & 1;
             for (int e = P.indptr[r]; e < P.indptr[r + 1]; e++) sy ^= hard[P.indices[e]] & 1;
-            if (sy) atomicOr(&U[uswz(brow, r >> 6, mw)], 1ull << (r & 63));
+            if (sy) atomicOr(&U[uix(brow, r >> 6)], 1ull << (r & 63));
         }
         __syncthreads();
         int row = 0;
         unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0, d_nzw = 0, d_wops = 0, d_lops = 0, c_p3own = 0;
+        (void)d_wops; (void)d_lops; (void)c_p3own; (void)d_nzw;
         const long long t_sorted = OSD_CLOCK();
         bool finished = (P.rankH == 0);
         for (int base = 0; base < n && !finished; base += K) {
@@ -840,9 +844,9 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     for (int w = wq; w < mw; w++) {
                         unsigned long long xs[8];
 #pragma unroll
-                        for (int d = 0; d < 8; d++) xs[d] = U[uswz(rr[d], w, mw)];
+                        for (int d = 0; d < 8; d++) xs[d] = U[uix(rr[d], w)];
                         unsigned long long x = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
-                        for (int d = 8; d < cd; d++) x ^= U[uswz(cr2[d], w, mw)];     // columns heavier than 8 (not the circuit-level matrices)
+                        for (int d = 8; d < cd; d++) x ^= U[uix(cr2[d], w)];     // columns heavier than 8 (not the circuit-level matrices)
                         any |= (w == wq) ? (x & (~0ull << (row & 63))) : x;
                     }
                     if (!any) alive[c2] = 0;
@@ -891,9 +895,9 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
 #pragma unroll
                     for (int d = 0; d < 8; d++) rr[d] = (d < cd) ? (int)cr[d] : m;           // short columns point at the zero row m
 #pragma unroll
-                    for (int d = 0; d < 8; d++) xs[d] = U[uswz(rr[d], w, mw)];
+                    for (int d = 0; d < 8; d++) xs[d] = U[uix(rr[d], w)];
                     unsigned long long acc = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
-                    for (int d = 8; d < cd; d++) acc ^= U[uswz(cr[d], w, mw)];
+                    for (int d = 8; d < cd; d++) acc ^= U[uix(cr[d], w)];
                     R[t * mw + w] = acc;
                 }
                 __syncthreads();
@@ -990,15 +994,15 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 auto swap_bits = [&](int q, int a, int pp) {
                     const int wa = a >> 6, wp = pp >> 6;
                     const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (pp & 63);
-                    if (wp == wa) { U[uswz(q, wa, mw)] ^= abit ^ pbit; }
-                    else { const unsigned long long xa = U[uswz(q, wa, mw)], xp = U[uswz(q, wp, mw)]; U[uswz(q, wa, mw)] = xa ^ abit; U[uswz(q, wp, mw)] = xp ^ pbit; }
+                    if (wp == wa) { U[uix(q, wa)] ^= abit ^ pbit; }
+                    else { const unsigned long long xa = U[uix(q, wa)], xp = U[uix(q, wp)]; U[uix(q, wa)] = xa ^ abit; U[uix(q, wp)] = xp ^ pbit; }
                 };
                 auto add_mask = [&](int q, const unsigned long long *mk) {
-                    if (mw == 16) {                                          // all reads in flight before the first XOR (a rolled loop waits per word)
+                    if (!UG && mw == 16) {                                   // all reads in flight before the first XOR (a rolled loop waits per word)
                         ulonglong2 u[8], k2[8];
                         ulonglong2 *Uq = reinterpret_cast<ulonglong2 *>(U + q * 16);
                         const ulonglong2 *mk2 = reinterpret_cast<const ulonglong2 *>(mk);
-                        const int sz = (q >> 4) & 7;                         // uswz() on pairs of words
+                        const int sz = (q >> 4) & 7;                         // the row's swizzle on pairs of words
 #pragma unroll
                         for (int w = 0; w < 8; w++) u[w] = Uq[w ^ sz];
 #pragma unroll
@@ -1008,16 +1012,16 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
 #pragma unroll
                         for (int w = 0; w < 8; w++) Uq[w ^ sz] = u[w];
                     } else {
-                        for (int w0 = 0; w0 < mw; w0 += 8) {                 // 8 words in flight (rows live in HBM/L2 in the UG kernel)
-                            unsigned long long u[8];
+                        for (int w0 = 0; w0 < mw; w0 += 16) {                // 16 words in flight (rows live in HBM/L2 in the UG kernel)
+                            unsigned long long u[16];
 #pragma unroll
-                            for (int j2 = 0; j2 < 8; j2++) u[j2] = (w0 + j2 < mw) ? U[uswz(q, w0 + j2, mw)] : 0ull;
+                            for (int j2 = 0; j2 < 16; j2++) u[j2] = (w0 + j2 < mw) ? U[uix(q, w0 + j2)] : 0ull;
 #pragma unroll
-                            for (int j2 = 0; j2 < 8; j2++) if (w0 + j2 < mw) U[uswz(q, w0 + j2, mw)] = u[j2] ^ mk[w0 + j2];
+                            for (int j2 = 0; j2 < 16; j2++) if (w0 + j2 < mw) U[uix(q, w0 + j2)] = u[j2] ^ mk[w0 + j2];
                         }
                     }
                 };
-                if (!UG && !P.p2waves && !P.p3serial && nops > 0) {
+                if (!P.p3serial && nops > 0) {
                     // Measured on the circuit-level matrices: 3.5 % of the (row, operation) pairs change the row, so a per-operation
                     // "read two words, test, branch" is all latency.  Here a row reads the 2 + 16 words holding the positions the WHOLE
                     // block tests back to back and keeps one bit per operation and kind (ab: bit a_k, pb: bit pp_k); the wave visits only
@@ -1036,12 +1040,12 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                         const int qq = act ? q : m;                          // idle lanes look at the all-zero row
                         uint32_t ab, pb = 0u;
                         {
-                            const unsigned long long A0 = U[uswz(qq, ws, mw)], A1 = (ws + 1 < mw) ? U[uswz(qq, ws + 1, mw)] : 0ull;
+                            const unsigned long long A0 = U[uix(qq, ws)], A1 = (ws + 1 < mw) ? U[uix(qq, ws + 1)] : 0ull;
                             uint32_t Pw[kOsdBlock];
 #pragma unroll
                             for (int k = 0; k < kOsdBlock; k++) {
                                 const int pk = (k < nops) ? __builtin_amdgcn_readlane(ppv, k) : 0;
-                                Pw[k] = U32[2 * uswz(qq, pk >> 6, mw) + ((pk >> 5) & 1)];
+                                Pw[k] = U32[2 * uix(qq, pk >> 6) + ((pk >> 5) & 1)];
                             }
                             ab = (uint32_t)((A0 >> sh) | (sh ? (A1 << (64 - sh)) : 0ull)) & valid;             // positions row .. row + nops - 1
 #pragma unroll
@@ -1096,8 +1100,8 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     if (q >= m + 2 || q == m) continue;
                     for (int k = 0; k < nops; k++) {
                         const int a = __builtin_amdgcn_readfirstlane(opa[k]), pp = __builtin_amdgcn_readfirstlane(opp[k]), wa = a >> 6, wp = pp >> 6;
-                        const unsigned long long xa = U[uswz(q, wa, mw)];
-                        const unsigned long long xp = (wp == wa) ? xa : U[uswz(q, wp, mw)];
+                        const unsigned long long xa = U[uix(q, wa)];
+                        const unsigned long long xp = (wp == wa) ? xa : U[uix(q, wp)];
                         const bool ba = ((xa >> (a & 63)) & 1ull) != 0ull, bp = ((xp >> (pp & 63)) & 1ull) != 0ull;
 #ifdef QLDPC_OSD_TIMERS
                         { const unsigned long long bb = __ballot(ba || bp); if (bb) { d_wops++; d_lops += __builtin_popcountll(bb); } }
@@ -1138,7 +1142,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
         __syncthreads();
         for (int t = tid; t < row; t += T) {
             const int j = pvcol[t];
-            const int8_t bbit = (int8_t)((U[uswz(brow, t >> 6, mw)] >> (t & 63)) & 1ull);
+            const int8_t bbit = (int8_t)((U[uix(brow, t >> 6)] >> (t & 63)) & 1ull);
             sol[j] = (int8_t)((hard[j] ^ bbit) & 1);
         }
         __syncthreads();

@@ -238,7 +238,7 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
         {
             std::lock_guard<std::mutex> lk(g->mu);
             rc = minsum_decode_dispatch(g, B, P->d_synd.as<int8_t>(), P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(),
-                                        P->damping, P->clip, (P->flags & 0xFFFF) | (P->nanfree ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0), P->nanfree, P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
+                                        P->damping, P->clip, (P->flags & QLDPC_FLAG_PUBLIC_MASK) | (P->nanfree ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0), P->nanfree, P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
                                         P->d_conv.as<uint8_t>(), P->d_iter.as<int32_t>(), s);
         }
         if (rc != QLDPC_OK) return rc;

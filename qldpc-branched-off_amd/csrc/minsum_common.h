@@ -23,7 +23,8 @@ __device__ __forceinline__ double clip_nan(double q, double clip) {
 __device__ __forceinline__ bool prior_not_finite(double p) { return !(fabs(p) < INFINITY); }
 
 // internal flag (upper half of `flags`): the caller verified on the host that every prior is finite
-#define QLDPC_FLAG_INTERNAL_PRIOR_FINITE 0x10000
+#define QLDPC_FLAG_PUBLIC_MASK 0x0FFFFFFF          // flag bits callers may set (include/qldpc_hip.h)
+#define QLDPC_FLAG_INTERNAL_PRIOR_FINITE 0x40000000
 
 // reference src/decoding/kernels.py:339-342
 __device__ __forceinline__ double clip_only(double q, double clip) {

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(1024) void minsum_wg_kernel(WgArgs A) {
                         A.out_err[b * n + j] = (x < 0.0) ? 1 : 0;                            // kernels.py:349
                     }
                     if (tid == 0) { A.out_conv[b] = conv ? 1 : 0; A.out_iter[b] = conv ? it - 1 : max_iter - 1; }   // kernels.py:267,362
+                    if (A.fixed) __syncthreads();                                            // fixed-work mode goes on: the copy must finish before the variable pass rewrites V
                 }
             }
             if (done && !A.fixed) break;                                                     // uniform: every thread read the same flag
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
                         A.out_err[b * n + j] = (x < 0.0) ? 1 : 0;                            // kernels.py:349
                     }
                     if (tid == 0) { A.out_conv[b] = conv ? 1 : 0; A.out_iter[b] = conv ? it - 1 : max_iter - 1; }   // kernels.py:267,362
+                    if (A.fixed) __syncthreads();                                            // fixed-work mode goes on: the copy must finish before the variable pass rewrites V
                 }
             }
             if (done && !A.fixed) break;

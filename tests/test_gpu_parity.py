@@ -881,7 +881,8 @@ def test_random_irregular_graphs_all_kernels(L, oracle, monkeypatch):
             clip = float(rng.choice([20.0, 6.5, 50.0]))
             iters = int(rng.integers(1, 25))
             ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=iters, alpha=alpha, alpha_mode=mode, damping=damping, clip_llr=clip)
-            variants = [(0, None), (L.FLAG_FIXED_ITERS, None), (L.FLAG_KERNEL_STREAM, None), (L.FLAG_WG_ROWMAJOR, None), (L.FLAG_WG_EDGE_LANES, None)]
+            variants = [(0, None), (L.FLAG_FIXED_ITERS, None), (L.FLAG_KERNEL_STREAM, None), (L.FLAG_WG_ROWMAJOR, None), (L.FLAG_WG_EDGE_LANES, None),
+                        (L.FLAG_WG_ROWMAJOR | L.FLAG_FIXED_ITERS, None)]
             if n >= 2000:
                 variants.append((L.FLAG_WG_VGLOBAL, "1"))              # posteriors in global memory
                 variants.append((L.FLAG_WG_VGLOBAL | L.FLAG_WG_ROWMAJOR, "1"))
