@@ -35,12 +35,16 @@ def collective_device(backend, device=None):
     return torch.device("cpu")
 
 
-def allreduce_tally(tally, device=None, group=None):
+def allreduce_tally(tally, device=None, group=None, comm=None):
     """Sum the int64[16] tally over all ranks (the single collective of the path); identity when not distributed.
-    `device`: the rank's GPU index (used when the backend is RCCL; default = torch's current device)."""
+    `comm`: a `_lib.Comm` (native RCCL communicator of the C ABI, qldpc_tally_allreduce) -- used instead of torch.distributed when given,
+    so a launcher without PyTorch can run the N > 1 path.  `device`: the rank's GPU index (used when the torch backend is RCCL;
+    default = torch's current device)."""
+    t = np.ascontiguousarray(tally, dtype=np.int64)
+    if comm is not None:
+        return comm.allreduce(t)
     import torch
     import torch.distributed as dist
-    t = np.ascontiguousarray(tally, dtype=np.int64)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return t.copy()
     if isinstance(device, torch.device):

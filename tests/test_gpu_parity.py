@@ -1138,6 +1138,8 @@ def test_native_rccl_tally_allreduce(L):
     assert len(uid) == 128
     c2 = L.Comm.init_rank(1, 0, uid, 0)
     assert np.array_equal(c2.allreduce(t), t)
+    from qldpc_amd.parallel import allreduce_tally
+    assert np.array_equal(allreduce_tally(t, comm=c2), t)              # the host mirror's collective on the native communicator
     c2.close()
     with pytest.raises(L.QldpcError):
         L.Comm.init_all(L.device_count() + 1)
