@@ -1167,6 +1167,8 @@ int osd0_pipe_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t 
                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
 int osd0_fwd_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
                     const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
+int osd0_small_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled);
 
 // rank of H over GF(2) (host, once per graph): the sweep above can stop as soon as this many pivots exist
 int host_gf2_rank(const qldpc_graph *g) {
@@ -1218,6 +1220,11 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     OsdLdsArgs P;
     size_t lds = 0;
     handled = false;
+    if (!(flags & (QLDPC_FLAG_OSD_LDS | QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL | QLDPC_FLAG_OSD_P2WAVES |
+                   QLDPC_FLAG_OSD_P3SERIAL | QLDPC_FLAG_OSD_NOKILL))) {                      // small matrices: the literal elimination, one wave per shot
+        const int rcs = osd0_small_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, stream, handled);
+        if (rcs != QLDPC_OK || handled) return rcs;
+    }
     if ((flags & QLDPC_FLAG_OSD_FWD) && !(flags & (QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // the forward-elimination kernel (m <= 1024)
         const int rcf = osd0_fwd_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
         if (rcf != QLDPC_OK || handled) return rcf;

@@ -38,6 +38,20 @@ __device__ __forceinline__ void osd_radix_sort(const double *__restrict__ llr, i
     const int span = (((n + NW - 1) / NW) + 63) & ~63;                                      // positions per wave, a multiple of 64
     const int wbeg = wv * span, wend = min(n, wbeg + span);
     for (int j = tid; j < n; j += T) { keys[j] = osd_key(llr[j]); pa[j] = (uint16_t)j; }
+    if (n <= 512) {
+        // small matrices (code capacity): one pass -- position of column i = number of columns with a smaller key, or the same key and a
+        // smaller index.  n^2 / T uniform (broadcast) key reads per thread instead of 8 passes x 4 barriers: the OSD kernel's latency on a
+        // handful of shots is what a Monte-Carlo step of the early-exit pipeline waits for.
+        __syncthreads();
+        for (int i = tid; i < n; i += T) {
+            const unsigned long long ki = keys[i];
+            int rank = 0;
+            for (int j = 0; j < n; j++) { const unsigned long long kj = keys[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+            ordw[rank] = (uint16_t)i;
+        }
+        __syncthreads();
+        return;
+    }
     for (int pass = 0; pass < 8; pass++) {
         const int shift = 8 * pass;
         for (int e = tid; e < 256 * NW; e += T) cnt[e] = 0u;

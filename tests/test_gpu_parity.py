@@ -120,7 +120,7 @@ def test_circuit_level_golden(L, golden, oracle, tag):
             assert np.array_equal(sol2, ref2)
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
             # the general global-memory OSD kernel (used when m > 1024) must agree with the LDS-resident one
-            for kfl in (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED):   # ... and so must the forward-elimination and the pipelined kernels
+            for kfl in (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_P2WAVES, L.FLAG_OSD_P3SERIAL):   # ... and the other forms of the LDS kernel
                 sol3 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, flags=kfl)
                 sol4 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0,
                                            ordering=g[f"{s}_osd_ordering"][t], flags=kfl)
@@ -898,11 +898,12 @@ def test_random_irregular_graphs_all_kernels(L, oracle, monkeypatch):
 
 def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
     """Differential sweep of OSD-0 over seeded random matrices (dependent rows, empty rows, heavy and empty columns, ties in |llr|,
-    realisable and unrealisable syndromes) through its three kernels: row transform in LDS, in HBM/L2 (forced), and the global-memory
-    elimination (forced).  Solutions identical to the oracle's."""
+    realisable and unrealisable syndromes) through its kernels: the one-wave literal elimination (small matrices), the row transform in LDS
+    (round-1 and round-2 forms of its phases), in HBM/L2 (forced), the forward and pipelined variants, and the global-memory elimination (forced).
+    Solutions identical to the oracle's."""
     import ctypes as C
     rng = np.random.default_rng(4242)
-    for gi, (m, n, dens) in enumerate(((4, 9, 0.4), (20, 60, 0.15), (63, 200, 0.06), (64, 64, 0.1), (130, 700, 0.03), (257, 1500, 0.012), (70, 40, 0.1))):
+    for gi, (m, n, dens) in enumerate(((4, 9, 0.4), (20, 60, 0.15), (63, 200, 0.06), (64, 64, 0.1), (130, 700, 0.03), (257, 1500, 0.012), (70, 40, 0.1), (100, 600, 0.04), (128, 256, 0.05))):
         Hd = (rng.random((m, n)) < dens).astype(np.int8)
         if m > 6:
             Hd[5] = Hd[1] ^ Hd[2]; Hd[3] = 0
@@ -917,7 +918,9 @@ def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
         llr = rng.normal(1.0, 3.0, (B, n)); llr[0, : n // 3] = 1.25; llr[1] = np.round(llr[1])     # ties
         hard = (rng.random((B, n)) < 0.1).astype(np.int8)
         want = np.stack([oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)])
-        for env in (0, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_NOKILL):
+        # (0 = the one-wave literal elimination for m <= 128, n <= 1024, else the transform kernel; FLAG_OSD_LDS forces the latter)
+        for env in (0, L.FLAG_OSD_LDS, L.FLAG_OSD_LDS | L.FLAG_OSD_P2WAVES, L.FLAG_OSD_LDS | L.FLAG_OSD_P3SERIAL, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD,
+                    L.FLAG_OSD_PIPED, L.FLAG_OSD_NOKILL):
             sol = L.osd0_batch(graph, synd, llr, hard, flags=env)
             assert np.array_equal(sol, want), (gi, env, np.flatnonzero((sol != want).any(1)))
 
