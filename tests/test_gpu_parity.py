@@ -903,7 +903,7 @@ def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
     Solutions identical to the oracle's."""
     import ctypes as C
     rng = np.random.default_rng(4242)
-    for gi, (m, n, dens) in enumerate(((4, 9, 0.4), (20, 60, 0.15), (63, 200, 0.06), (64, 64, 0.1), (130, 700, 0.03), (257, 1500, 0.012), (70, 40, 0.1), (100, 600, 0.04), (128, 256, 0.05))):
+    for gi, (m, n, dens) in enumerate(((4, 9, 0.4), (20, 60, 0.15), (63, 200, 0.06), (64, 64, 0.1), (130, 700, 0.03), (257, 1500, 0.012), (70, 40, 0.1), (100, 600, 0.04), (128, 256, 0.05), (200, 500, 0.03), (250, 90, 0.08))):
         Hd = (rng.random((m, n)) < dens).astype(np.int8)
         if m > 6:
             Hd[5] = Hd[1] ^ Hd[2]; Hd[3] = 0
