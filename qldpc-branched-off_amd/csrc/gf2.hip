@@ -832,9 +832,9 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
             }
             __syncthreads();
             // drops every still-alive column of the chunk from c0 on that is dependent on the pivots found so far (one thread per column)
-            auto kill_pass = [&](int c0) {
+            auto kill_pass = [&](int c0, int t0, int tstride) {               // threads t0 = 0 .. tstride - 1 take part
                 const int wq = row >> 6;
-                for (int c2 = c0 + tid; c2 < L; c2 += T) {
+                for (int c2 = c0 + t0; c2 < L; c2 += tstride) {
                     if (!alive[c2]) continue;
                     const uint16_t *cr2 = colrows + c2 * cd;
                     int rr[8];                                           // the column's support once (cd <= 8; short columns point at the zero row m)
@@ -852,10 +852,11 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     if (!any) alive[c2] = 0;
                 }
             };
+            bool kill_due = false;                                           // a block met dependent columns: test the rest of the chunk (deferred, see phase 2)
             if (row > 0 && !P.nokill) {                                      // a fresh chunk late in the sweep is mostly dependent columns: one pass up
                 long long tk = OSD_CLOCK();                                    // front instead of one serial pivot step per dependent column
                 d_kills++;
-                kill_pass(0);
+                kill_pass(0, tid, T);
                 __syncthreads();
                 c_kill += OSD_CLOCK() - tk;
             }
@@ -928,7 +929,13 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
 #ifdef QLDPC_OSD_TIMERS
                         d_nzw += S.nzw;
 #endif
+                    } else if (kill_due) {
+                        // the other waves: the dependent-column tests an earlier block asked for, against the transform as it stands (without this
+                        // block's pivots: a dependent column stays dependent, the test is only one block less eager); the block's own columns
+                        // lie before blk[3], so the two do not touch the same alive[] entries
+                        kill_pass(blk[3], tid - 64, T - 64);
                     }
+                    if (kill_due) { d_kills++; kill_due = false; }
                     __syncthreads();
                     nops = blk[1]; anydep = blk[2];
                 } else {
@@ -1119,10 +1126,14 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 if (row >= P.rankH || row >= m) { finished = true; break; }
                 // ---- dependent columns were met: drop every column of the chunk that is dependent by now ----
                 if (anydep && !P.nokill) {
-                    d_kills++;
-                    kill_pass(blk[3]);
-                    __syncthreads();
-                    c_kill += OSD_CLOCK() - tp;
+                    if (!UG && !P.p2waves) {
+                        kill_due = true;                                     // done by the idle waves beside the next block's pivot chain (phase 2 above)
+                    } else {
+                        d_kills++;
+                        kill_pass(blk[3], tid, T);
+                        __syncthreads();
+                        c_kill += OSD_CLOCK() - tp;
+                    }
                 }
             }
             __syncthreads();      // nobody may refill alive[]/sidx[] while others still use them
