@@ -678,73 +678,6 @@ constexpr int kOsdBlock = QLDPC_OSD_BLOCK;      // columns resolved per block (4
 static_assert(kOsdBlock <= 16, "one wave per column, at most 4 columns per wave with 256-thread blocks");
 __device__ __forceinline__ unsigned long long r_mask_word(const unsigned long long *R, int t, int mw, int w) { return R[t * mw + w]; }
 
-// U is stored row-major with an XOR swizzle of the word index when rows are 16 words (128 B): conflict-free row-parallel updates
-// (rows of 16 words belong to threads as q = 16 * lane + (wave + lane) % 16, see phase 3: the swizzle follows the lane and moves PAIRS of
-// words, so that a row can also be read and written 16 bytes at a time)
-__device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ ((q >> 3) & 14)) : w); }
-
-// ---- phase 2 of the LDS kernel in ONE wave, registers only (rows of <= 16 words) ----
-// lane = 4 * w + g holds word w of the four columns t = 4 i + g (i = 0..3) of the block.  A pivot step is: one ballot over all 16 words
-// of column t (first live set bit, kernels.py:71-75), two lane reads, the column turned into the elimination mask, the mask handed to
-// the other three lanes of every quad by a DPP quad broadcast, and for each register that still holds later columns two ballots (bits
-// a and pp of those columns), the swap (kernels.py:79-82) and the XOR (kernels.py:88-92) -- no LDS access and no barrier inside the
-// chain; the step index is a template parameter so every register index and DPP pattern is static.
-struct QuadPivot {
-    unsigned long long X[4];       // the lane's word of columns g, 4 + g, 8 + g, 12 + g
-    unsigned long long live;       // positions >= lrow within the lane's word
-    int lrow, nops;
-    uint32_t depmask;              // columns found dependent
-    int oppv, optv;                // lane k: pivot position / column index of operation k
-    bool stop;
-    unsigned nzw;                  // diagnostic build: non-zero words over the masks
-};
-
-template <int G>
-__device__ __forceinline__ unsigned long long quad_bcast(unsigned long long x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, G * 0x55, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), G * 0x55, 0xF, 0xF, false);
-    return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-__device__ __forceinline__ unsigned long long sext64(int f) { return ((unsigned long long)(uint32_t)f << 32) | (uint32_t)f; }
-
-template <int T>
-__device__ __forceinline__ void quad_pivot_step(QuadPivot &S, unsigned long long *R, int mw, int lane, int rankH, int m) {
-    constexpr int IT = T >> 2, GT = T & 3;
-    const int g = lane & 3, w = lane >> 2;
-    const unsigned long long owners = 0x1111111111111111ull << GT;
-    const unsigned long long mword = S.X[IT] & S.live;
-    const unsigned long long bal = __ballot(mword != 0ull) & owners;
-    if (bal == 0ull) { S.depmask |= 1u << T; return; }                                      // dependent on the pivots so far
-    const int src = __builtin_ctzll(bal);
-    const unsigned long long pword = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), src) << 32) |
-                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, src);
-    const int wp = src >> 2, pb = __builtin_ctzll(pword), pp = wp * 64 + pb, a = S.lrow, wa = a >> 6;
-    const unsigned long long al = (w == wa) ? (1ull << (a & 63)) : 0ull, pl = (w == wp) ? (1ull << pb) : 0ull;
-    // the pivot column becomes the elimination mask: bits a <-> pp swapped (bit pp is 1), then bit a cleared
-    const bool olda = (__ballot((S.X[IT] & al) != 0ull) & owners) != 0ull;
-    unsigned long long rm = olda ? (S.X[IT] | pl) : (S.X[IT] & ~pl);
-    rm &= ~al;                                                                               // (in this order: a == pp must end with bit a clear)
-    if (g == GT && w < mw) R[T * mw + w] = rm;
-#ifdef QLDPC_OSD_TIMERS
-    S.nzw += (unsigned)__builtin_popcountll(__ballot(rm != 0ull) & owners);
-#endif
-    const unsigned long long rmq = quad_bcast<GT>(rm), sw = al | pl;
-#pragma unroll
-    for (int i = IT; i < 4; i++) {
-        if (4 * i + 3 <= T) continue;                                                        // no later column in this register
-        const unsigned long long x = S.X[i];
-        const uint32_t na = (uint32_t)(__ballot((x & al) != 0ull) >> (4 * wa)), np = (uint32_t)(__ballot((x & pl) != 0ull) >> (4 * wp));
-        int fa = __builtin_amdgcn_sbfe((int)na, g, 1), fp = __builtin_amdgcn_sbfe((int)np, g, 1);          // 0 / -1: bit a, bit pp of the lane's column
-        if (i == IT) { const int later = (g > GT) ? -1 : 0; fa &= later; fp &= later; }      // columns <= t of this register are finished
-        S.X[i] = x ^ (sext64(fa ^ fp) & sw) ^ (sext64(fp) & rmq);                            // swap, then add the pivot row where bit a is set
-    }
-    S.live &= ~al;
-    S.oppv = (lane == S.nops) ? pp : S.oppv;
-    S.optv = (lane == S.nops) ? T : S.optv;
-    S.nops++; S.lrow++;
-    if (S.lrow >= rankH || S.lrow >= m) S.stop = true;                                       // full rank: the remaining columns cannot pivot
-}
-
 // Position-space formulation.  T (current rows = T * original rows, rows in their CURRENT physical order, i.e. after the
 // reference's swaps kernels.py:79-82) is kept as U = T^T: U[q] bit p = T[p][q].  Rows 0..m-1 of U belong to the original
 // rows, row m is all zero (padding target of short columns) and row m+1 carries the right-hand side b (it transforms like
@@ -1045,6 +978,10 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                         const int q = rowq(qb);
                         const bool act = (q < m + 2) && (q != m);
                         const int qq = act ? q : m;                          // idle lanes look at the all-zero row
+                        if (!UG) {                                           // rows in LDS: osd_common.h
+                            osd_rows_apply(U + qq * mw, (mw == 16) ? ((qq >> 3) & 14) : 0, act, row, nops, mw, ppv, ptv, R, tid, d_wops, d_lops);
+                            continue;
+                        }
                         uint32_t ab, pb = 0u;
                         {
                             const unsigned long long A0 = U[uix(qq, ws)], A1 = (ws + 1 < mw) ? U[uix(qq, ws + 1)] : 0ull;

@@ -144,4 +144,162 @@ __device__ __forceinline__ void osd_radix_sort(const double *__restrict__ llr, i
     __syncthreads();
 }
 
+
+// U is stored row-major with an XOR swizzle of the word index when rows are 16 words (128 B): conflict-free row-parallel updates
+// (rows of 16 words belong to threads as q = 16 * lane + (wave + lane) % 16, see phase 3: the swizzle follows the lane and moves PAIRS of
+// words, so that a row can also be read and written 16 bytes at a time)
+__device__ __forceinline__ int uswz(int q, int w, int mw) { return q * mw + ((mw == 16) ? (w ^ ((q >> 3) & 14)) : w); }
+
+// ---- phase 2 of the LDS kernel in ONE wave, registers only (rows of <= 16 words) ----
+// lane = 4 * w + g holds word w of the four columns t = 4 i + g (i = 0..3) of the block.  A pivot step is: one ballot over all 16 words
+// of column t (first live set bit, kernels.py:71-75), two lane reads, the column turned into the elimination mask, the mask handed to
+// the other three lanes of every quad by a DPP quad broadcast, and for each register that still holds later columns two ballots (bits
+// a and pp of those columns), the swap (kernels.py:79-82) and the XOR (kernels.py:88-92) -- no LDS access and no barrier inside the
+// chain; the step index is a template parameter so every register index and DPP pattern is static.
+struct QuadPivot {
+    unsigned long long X[4];       // the lane's word of columns g, 4 + g, 8 + g, 12 + g
+    unsigned long long live;       // positions >= lrow within the lane's word
+    int lrow, nops;
+    uint32_t depmask;              // columns found dependent
+    int oppv, optv;                // lane k: pivot position / column index of operation k
+    bool stop;
+    unsigned nzw;                  // diagnostic build: non-zero words over the masks
+};
+
+template <int G>
+__device__ __forceinline__ unsigned long long quad_bcast(unsigned long long x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, G * 0x55, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), G * 0x55, 0xF, 0xF, false);
+    return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ unsigned long long sext64(int f) { return ((unsigned long long)(uint32_t)f << 32) | (uint32_t)f; }
+
+template <int T>
+__device__ __forceinline__ void quad_pivot_step(QuadPivot &S, unsigned long long *R, int mw, int lane, int rankH, int m) {
+    constexpr int IT = T >> 2, GT = T & 3;
+    const int g = lane & 3, w = lane >> 2;
+    const unsigned long long owners = 0x1111111111111111ull << GT;
+    const unsigned long long mword = S.X[IT] & S.live;
+    const unsigned long long bal = __ballot(mword != 0ull) & owners;
+    if (bal == 0ull) { S.depmask |= 1u << T; return; }                                      // dependent on the pivots so far
+    const int src = __builtin_ctzll(bal);
+    const unsigned long long pword = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), src) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, src);
+    const int wp = src >> 2, pb = __builtin_ctzll(pword), pp = wp * 64 + pb, a = S.lrow, wa = a >> 6;
+    const unsigned long long al = (w == wa) ? (1ull << (a & 63)) : 0ull, pl = (w == wp) ? (1ull << pb) : 0ull;
+    // the pivot column becomes the elimination mask: bits a <-> pp swapped (bit pp is 1), then bit a cleared
+    const bool olda = (__ballot((S.X[IT] & al) != 0ull) & owners) != 0ull;
+    unsigned long long rm = olda ? (S.X[IT] | pl) : (S.X[IT] & ~pl);
+    rm &= ~al;                                                                               // (in this order: a == pp must end with bit a clear)
+    if (g == GT && w < mw) R[T * mw + w] = rm;
+#ifdef QLDPC_OSD_TIMERS
+    S.nzw += (unsigned)__builtin_popcountll(__ballot(rm != 0ull) & owners);
+#endif
+    const unsigned long long rmq = quad_bcast<GT>(rm), sw = al | pl;
+#pragma unroll
+    for (int i = IT; i < 4; i++) {
+        if (4 * i + 3 <= T) continue;                                                        // no later column in this register
+        const unsigned long long x = S.X[i];
+        const uint32_t na = (uint32_t)(__ballot((x & al) != 0ull) >> (4 * wa)), np = (uint32_t)(__ballot((x & pl) != 0ull) >> (4 * wp));
+        int fa = __builtin_amdgcn_sbfe((int)na, g, 1), fp = __builtin_amdgcn_sbfe((int)np, g, 1);          // 0 / -1: bit a, bit pp of the lane's column
+        if (i == IT) { const int later = (g > GT) ? -1 : 0; fa &= later; fp &= later; }      // columns <= t of this register are finished
+        S.X[i] = x ^ (sext64(fa ^ fp) & sw) ^ (sext64(fp) & rmq);                            // swap, then add the pivot row where bit a is set
+    }
+    S.live &= ~al;
+    S.oppv = (lane == S.nops) ? pp : S.oppv;
+    S.optv = (lane == S.nops) ? T : S.optv;
+    S.nops++; S.lrow++;
+    if (S.lrow >= rankH || S.lrow >= m) S.stop = true;                                       // full rank: the remaining columns cannot pivot
+}
+
+
+// ---- phase 3 for rows of <= 16 words in LDS: the operations of one block applied to the lane's row (gf2.hip explains why it looks like this)
+// rowbase[w ^ swz] is word w of the row (swz: the row's pair swizzle, 0 for an unswizzled vector); `act` = the lane has a row; all 64 lanes
+// of a wave call this together.  Operation k: positions a_k = row0 + k and pp_k (lane k of every 16 of ppv), elimination mask
+// R + ptv_k * mw.  Only 3.5 % of the (row, operation) pairs change a row of the circuit-level transforms: the row reads the 2 + 16 words
+// holding the tested positions of the WHOLE block back to back, keeps one bit per operation and kind (ab: bit a_k, pb: bit pp_k), the wave
+// visits only operations some lane has a bit for, and a changed row updates its later bits from two ballots instead of reading again.
+__device__ __forceinline__ void osd_rows_apply(unsigned long long *rowbase, int swz, bool act, int row0, int nops, int mw, int ppv, int ptv,
+                                               const unsigned long long *R, int tid, unsigned long long &d_wops, unsigned long long &d_lops) {
+    const int ws = row0 >> 6, sh = row0 & 63;
+    const uint32_t valid = (1u << nops) - 1u;
+    const uint32_t *row32 = reinterpret_cast<const uint32_t *>(rowbase);
+    // lanes 0-15 of every 32 stand for position a_j = row0 + j, lanes 16-31 for pp_j (j = lane % 16): see the bit updates below
+    const int j16 = tid & 15, mypos = (j16 < nops) ? ((tid & 16) ? ppv : row0 + j16) : 0;
+    uint32_t ab, pb = 0u;
+    {
+        const unsigned long long A0 = rowbase[ws ^ swz], A1 = (ws + 1 < mw) ? rowbase[(ws + 1) ^ swz] : 0ull;
+        uint32_t Pw[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int pk = (k < nops) ? __builtin_amdgcn_readlane(ppv, k) : 0;
+            Pw[k] = row32[2 * ((pk >> 6) ^ swz) + ((pk >> 5) & 1)];
+        }
+        ab = (uint32_t)((A0 >> sh) | (sh ? (A1 << (64 - sh)) : 0ull)) & valid;             // positions row0 .. row0 + nops - 1
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int pk = __builtin_amdgcn_readlane(ppv, k);
+            pb |= ((Pw[k] >> (pk & 31)) & 1u) << k;
+        }
+        pb &= valid;
+        if (!act) { ab = 0u; pb = 0u; }
+    }
+    int kdone = -1;
+    for (;;) {
+        uint32_t x = ab | pb;                                                               // OR over the wave
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);        // quad_perm [2,3,0,1]
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);       // row_half_mirror
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);       // row_mirror
+        uint32_t wtb = (uint32_t)__builtin_amdgcn_readlane((int)x, 0) | (uint32_t)__builtin_amdgcn_readlane((int)x, 16) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)x, 32) | (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+        if (kdone >= 0) wtb &= ~1u << kdone;
+        if (wtb == 0u) break;
+        const int k = __builtin_ctz(wtb);
+        kdone = k;
+        const int ppk = __builtin_amdgcn_readlane(ppv, k), a = row0 + k;
+        const unsigned long long *mk = R + __builtin_amdgcn_readlane(ptv, k) * mw;
+        // what operation k does to the bits the later operations j > k test in a row it changes: the swap puts the row's old bit a_k at
+        // position pp_k (xx: bit j = (a_j == pp_k), bit 16 + j = (pp_j == pp_k)); the XOR flips them by the mask's bits at those
+        // positions (mm: bit j = mask_k[a_j], bit 16 + j = mask_k[pp_j])
+        const bool later = (j16 > k) && (j16 < nops);
+        const uint32_t mword = reinterpret_cast<const uint32_t *>(mk)[2 * (mypos >> 6) + ((mypos >> 5) & 1)];
+        const uint32_t xx = (uint32_t)__ballot(later && mypos == ppk);
+        const uint32_t mm = (uint32_t)__ballot(later && ((mword >> (mypos & 31)) & 1u));
+        const bool ba = (ab >> k) & 1u, bp = (pb >> k) & 1u;
+#ifdef QLDPC_OSD_TIMERS
+        { d_wops++; d_lops += __builtin_popcountll(__ballot(ba || bp)); }
+#endif
+        if (ba != bp) {                                                                     // kernels.py:79-82: swap bits a <-> pp
+            const int wa = a >> 6, wp = ppk >> 6;
+            const unsigned long long abit = 1ull << (a & 63), pbit = 1ull << (ppk & 63);
+            if (wp == wa) { rowbase[wa ^ swz] ^= abit ^ pbit; }
+            else { const unsigned long long xa = rowbase[wa ^ swz], xp = rowbase[wp ^ swz]; rowbase[wa ^ swz] = xa ^ abit; rowbase[wp ^ swz] = xp ^ pbit; }
+            const uint32_t sa = xx & 0xFFFFu, sp = xx >> 16;
+            ab = ba ? (ab | sa) : (ab & ~sa);
+            pb = ba ? (pb | sp) : (pb & ~sp);
+        }
+        if (bp) {                                                                           // bit a after the swap: add the pivot row (kernels.py:88-92)
+            if (mw == 16) {                                                                 // all reads in flight before the first XOR
+                ulonglong2 u[8], k2[8];
+                ulonglong2 *Uq = reinterpret_cast<ulonglong2 *>(rowbase);
+                const ulonglong2 *mk2 = reinterpret_cast<const ulonglong2 *>(mk);
+                const int sz = swz >> 1;
+#pragma unroll
+                for (int w = 0; w < 8; w++) u[w] = Uq[w ^ sz];
+#pragma unroll
+                for (int w = 0; w < 8; w++) k2[w] = mk2[w];
+#pragma unroll
+                for (int w = 0; w < 8; w++) { u[w].x ^= k2[w].x; u[w].y ^= k2[w].y; }
+#pragma unroll
+                for (int w = 0; w < 8; w++) Uq[w ^ sz] = u[w];
+            } else {
+                for (int w = 0; w < mw; w++) rowbase[w ^ swz] ^= mk[w];
+            }
+            ab ^= mm & 0xFFFFu;
+            pb ^= mm >> 16;
+        }
+    }
+}
+
 }  // namespace qldpc
