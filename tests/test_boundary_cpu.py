@@ -224,3 +224,20 @@ def test_collective_device_rule():
     finally:
         del os.environ["LOCAL_RANK"]
     assert parallel.local_device() == 0
+
+
+def test_flag_constants_follow_the_header():
+    """Every QLDPC_FLAG_* of include/qldpc_hip.h has a `_lib.FLAG_*` twin with the same value (and no two public flags share a bit)."""
+    import re
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd import _lib
+    with open(_lib.HEADER_PATH) as fh:
+        defs = dict(re.findall(r"#define\s+QLDPC_FLAG_(\w+)\s+(0x[0-9a-fA-F]+)", fh.read()))
+    assert len(defs) >= 18
+    seen = {}
+    for name, val in defs.items():
+        v = int(val, 16)
+        assert getattr(_lib, "FLAG_" + name) == v, name
+        assert v & (v - 1) == 0 and v not in seen, (name, seen.get(v))
+        assert v < 0x10000000                      # the public mask (csrc/minsum_common.h: QLDPC_FLAG_PUBLIC_MASK)
+        seen[v] = name
