@@ -65,6 +65,8 @@ extern "C" {
                                            a block's tested bits at once */
 #define QLDPC_FLAG_OSD_LDS 0x20000      /* OSD-0: the row-transform kernel even for small matrices (m <= 128, n <= 1024), which otherwise take the
                                            literal one-wave-per-shot elimination */
+#define QLDPC_FLAG_WG_IDXLOAD 0x40000   /* workgroup-per-shot decoder: reload the row's column indices every iteration even where a thread owns one
+                                           row for the whole launch (m <= 1024) and keeps them in registers by default */
 #define QLDPC_FLAG_WG_VGLOBAL 0x100     /* workgroup-per-shot decoder: posteriors in HBM/L2 even when they fit LDS (the large-graph form) */
 #define QLDPC_FLAG_WG_GENERIC 0x200     /* workgroup-per-shot decoder: the any-input kernel even for host-verified clean inputs */
 #define QLDPC_FLAG_OSD_UG 0x400         /* OSD-0: row transform in HBM/L2 even when it fits LDS (the m > 1024 form) */

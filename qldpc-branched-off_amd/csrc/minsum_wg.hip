@@ -13,6 +13,7 @@
 // damping != 1 needs Q_old per edge (245 KB per shot): it lives in a slot-major HBM/L2 slab per workgroup (DAMP variants).
 #include "common.h"
 #include "minsum_common.h"
+#include "osd_common.h"      // OSD_CLOCK / osd_timer_buffer: the diagnostic build (make timers) also times the phases of the lean kernel
 
 #include <cmath>
 #include <cstdlib>
@@ -41,6 +42,7 @@ struct WgArgs {
     int qstride;           // doubles per workgroup in qold
     double *vglobal;       // VG kernels: posteriors V[n] per workgroup in HBM/L2 (graphs whose V does not fit next to the check states in LDS)
     unsigned long long *clk;   // QLDPC_FLAG_CLOCK_PROBE buffer of the launching plan, else NULL
+    unsigned long long *dbg;   // diagnostic build: phase cycle counters (else NULL)
     int *queue;            // next shot to decode (zeroed before the launch): shots are handed out one at a time, so the
                            // workgroups finish together although their shots run 1..max_iter iterations
 };
@@ -174,14 +176,11 @@ __device__ __forceinline__ double flip_sign(double x, uint32_t signword) { retur
 // FULL: every lane of the wave has all 8 edges of this chunk (rows are handed out in degree order, so that is the rule, not the
 // exception): no per-edge predicate, which is 4 of the ~21 instructions an edge costs.
 template <bool NANSEL, bool FIRST, bool DAMP, bool FULL>
-__device__ __forceinline__ void wg_lean_chunk(const uint16_t *__restrict__ ec, int m, const double *__restrict__ V, int deg, int k0, double p1s, double p2s,
-                                              uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, double damping, double one_minus_d,
-                                              double *__restrict__ qo, bool store_q, bool &par, double &min1, double &min2, int &arg, uint32_t &nlo,
-                                              uint32_t &nhi) {
-    uint32_t c[8];
+__device__ __forceinline__ void wg_lean_chunk_cols(const uint32_t (&c)[8], int m, const double *__restrict__ V, int deg, int k0, double p1s, double p2s,
+                                                   uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, double damping, double one_minus_d,
+                                                   double *__restrict__ qo, bool store_q, bool &par, double &min1, double &min2, int &arg, uint32_t &nlo,
+                                                   uint32_t &nhi) {
     double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) c[u] = ec[(size_t)(k0 + u) * m];                            // table rows are padded to a multiple of 8 with column 0
 #pragma unroll
     for (int u = 0; u < 8; u++) v[u] = V[c[u]];
     double qprev[8];
@@ -216,6 +215,41 @@ __device__ __forceinline__ void wg_lean_chunk(const uint16_t *__restrict__ ec, i
     if (k0 < 32) nlo |= cb << k0; else nhi |= cb << (k0 - 32);
 }
 
+template <bool NANSEL, bool FIRST, bool DAMP, bool FULL>
+__device__ __forceinline__ void wg_lean_chunk(const uint16_t *__restrict__ ec, int m, const double *__restrict__ V, int deg, int k0, double p1s, double p2s,
+                                              uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, double damping, double one_minus_d,
+                                              double *__restrict__ qo, bool store_q, bool &par, double &min1, double &min2, int &arg, uint32_t &nlo,
+                                              uint32_t &nhi) {
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) c[u] = ec[(size_t)(k0 + u) * m];                            // table rows are padded to a multiple of 8 with column 0
+    wg_lean_chunk_cols<NANSEL, FIRST, DAMP, FULL>(c, m, V, deg, k0, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, damping, one_minus_d, qo, store_q, par, min1,
+                                                  min2, arg, nlo, nhi);
+}
+
+// RIDX kernels (m <= blockDim: a thread owns ONE row for the whole launch, check degree <= 40): the row's column indices stay in 20 registers,
+// two per register, so the check pass has no index loads at all (in-kernel stamps: 18.9 k -> 15.5 k cycles per iteration for the check pass)
+constexpr int kIdxChunks = 5;
+template <bool NANSEL, bool FIRST>
+__device__ __forceinline__ void wg_lean_row_idx(const uint32_t (&idx)[4 * kIdxChunks], int m, const double *__restrict__ V, int deg, double p1s, double p2s,
+                                                uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, bool &par, double &min1, double &min2,
+                                                int &arg, uint32_t &nlo, uint32_t &nhi) {
+#pragma unroll
+    for (int ch = 0; ch < kIdxChunks; ch++) {
+        const int k0 = 8 * ch;
+        if (!__any(k0 < deg)) break;
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { c[u] = idx[4 * ch + u / 2] & 0xFFFFu; c[u + 1] = idx[4 * ch + u / 2] >> 16; }
+        if (__all(k0 + 8 <= deg))
+            wg_lean_chunk_cols<NANSEL, FIRST, false, true>(c, m, V, deg, k0, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, 1.0, 0.0, nullptr, false, par, min1, min2,
+                                                           arg, nlo, nhi);
+        else
+            wg_lean_chunk_cols<NANSEL, FIRST, false, false>(c, m, V, deg, k0, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, 1.0, 0.0, nullptr, false, par, min1, min2,
+                                                            arg, nlo, nhi);
+    }
+}
+
 template <bool NANSEL, bool FIRST, bool DAMP>
 __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int m, const double *__restrict__ V, int deg, double p1s, double p2s,
                                             uint32_t ip_lo, uint32_t ip_hi, int argp, double clip, double nclip, double damping, double one_minus_d,
@@ -231,7 +265,7 @@ __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int
     }
 }
 
-template <bool NANSEL, bool VG, bool DAMP>
+template <bool NANSEL, bool VG, bool DAMP, bool RIDX = false>
 __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     extern __shared__ unsigned char lds[];
     double *V;
@@ -246,6 +280,18 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     const int deg_own = (tid < m) ? (int)A.degr[tid] : 0;                                    // the thread's first row slot, constant over shots
     const int row_own = (tid < m) ? A.row_of_slot[tid] : 0;
     if (tid == 0) { SP[m] = make_double2(0.0, 0.0); SI[m] = make_uint2(0u, 0u); }            // dummy check read by padded column slots
+    uint32_t idx[4 * kIdxChunks];                                                            // RIDX: the row's columns, two per register (unused slots: column 0)
+    if (RIDX) {
+#pragma unroll
+        for (int p2 = 0; p2 < 4 * kIdxChunks; p2++) {
+            const int k = 2 * p2;
+            const uint32_t lo = (tid < m && k < A.rdeg) ? A.ell_col[(size_t)k * m + tid] : 0u, hi = (tid < m && k + 1 < A.rdeg) ? A.ell_col[(size_t)(k + 1) * m + tid] : 0u;
+            idx[p2] = lo | (hi << 16);
+        }
+    }
+    long long t_chk = 0, t_b1 = 0, t_frz = 0, t_var = 0, t_b2 = 0;                           // (diagnostic build only: OSD_CLOCK() is 0 otherwise)
+    unsigned long long n_it = 0;
+    (void)t_chk; (void)t_b1; (void)t_frz; (void)t_var; (void)t_b2; (void)n_it;
 
     for (;;) {
         if (tid == 0) unsat[2] = atomicAdd(A.queue, 1);                                       // unsat[2]: the shot this workgroup decodes next
@@ -258,6 +304,7 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
         bool done = false;
         __syncthreads();
         for (int it = 0; it <= max_iter; it++) {
+            long long tq = OSD_CLOCK();
             if (A.fixed || !done) {
                 const double alpha = (it < max_iter) ? A.alpha[it] : 0.0;
                 if (!DAMP && A.edge_lanes) {
@@ -334,6 +381,8 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
                     int arg = 127;
                     uint32_t nlo = 0u, nhi = 0u;
                     if (it == 0) {
+                        if (RIDX) wg_lean_row_idx<NANSEL, true>(idx, m, V, deg, 0.0, 0.0, 0u, 0u, 127, clip, nclip, par, min1, min2, arg, nlo, nhi);
+                        else
                         wg_lean_row<NANSEL, true, DAMP>(A.ell_col + i, m, V, deg, 0.0, 0.0, 0u, 0u, 127, clip, nclip, damping, one_minus_d, DAMP ? Qo + i : nullptr,
                                                         it < max_iter, par, min1, min2, arg, nlo, nhi);
                     } else {
@@ -344,6 +393,8 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
                             const double2 t = SP[i]; const uint2 u = SI[i];
                             p1s = t.x; p2s = t.y; argp = (int)(u.y >> 24); ip_lo = u.x; ip_hi = u.y & 0x00FFFFFFu;
                         }
+                        if (RIDX) wg_lean_row_idx<NANSEL, false>(idx, m, V, deg, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, par, min1, min2, arg, nlo, nhi);
+                        else
                         wg_lean_row<NANSEL, false, DAMP>(A.ell_col + i, m, V, deg, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, damping, one_minus_d,
                                                          DAMP ? Qo + i : nullptr, it < max_iter, par, min1, min2, arg, nlo, nhi);
                     }
@@ -355,7 +406,9 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
                     }
                 }
             }
+            t_chk += OSD_CLOCK() - tq; tq = OSD_CLOCK();
             __syncthreads();
+            t_b1 += OSD_CLOCK() - tq; tq = OSD_CLOCK();
             if (!done) {                                                                     // freeze test (kernels.py:361-364)
                 const bool conv = (it >= 1) && (unsat[it & 1] == 0);
                 if (conv || it == max_iter) {
@@ -372,6 +425,7 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
             if (done && !A.fixed) break;
             if (it == max_iter) break;
             if (tid == 0) unsat[(it + 1) & 1] = 0;
+            t_frz += OSD_CLOCK() - tq; tq = OSD_CLOCK(); n_it++;
             // variable pass: values_it.  Same batching: the column's edge slots are loaded 4 at a time, then the 4 check states.
             for (int c = tid; c < n; c += T) {                                               // c = column slot
                 const int j = A.col_of_slot[c], cdj = A.degc[c];
@@ -414,10 +468,18 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
                 }
                 V[j] = s + pr;                                                               // kernels.py:320
             }
+            t_var += OSD_CLOCK() - tq; tq = OSD_CLOCK();
             __syncthreads();
+            t_b2 += OSD_CLOCK() - tq;
         }
         __syncthreads();
     }
+#ifdef QLDPC_OSD_TIMERS
+    if (A.dbg && (tid & 63) == 0) {          // per-wave sums (the reader divides by the wave-iterations in [1])
+        atomicAdd(&A.dbg[1], n_it); atomicAdd(&A.dbg[2], (unsigned long long)t_chk); atomicAdd(&A.dbg[3], (unsigned long long)t_b1);
+        atomicAdd(&A.dbg[4], (unsigned long long)t_frz); atomicAdd(&A.dbg[5], (unsigned long long)t_var); atomicAdd(&A.dbg[6], (unsigned long long)t_b2);
+    }
+#endif
     clk_end(A.clk, clk0);
 }
 
@@ -472,6 +534,7 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     QLDPC_HIP_TRY(hipMemsetAsync(g->ws_queue.p, 0, 16, stream));
     A.queue = g->ws_queue.as<int>();
     A.clk = g->clk_probe;
+    A.dbg = osd_timer_buffer();      // NULL unless built with -DQLDPC_OSD_TIMERS (make timers)
     if ((rcq = g->ws_prior.ensure((size_t)g->n * 8)) != QLDPC_OK) return rcq;                // the prior in column-slot order (per launch: it is an input)
     hipLaunchKernelGGL(permute_prior_kernel, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, stream, g->n, A.col_of_slot, d_prior, g->ws_prior.as<double>());
     A.prior_s = g->ws_prior.as<double>();
@@ -495,7 +558,10 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
           {minsum_wg_lean_kernel<false, true, false>, minsum_wg_lean_kernel<false, true, true>}},
          {{minsum_wg_lean_kernel<true, false, false>, minsum_wg_lean_kernel<true, false, true>},
           {minsum_wg_lean_kernel<true, true, false>, minsum_wg_lean_kernel<true, true, true>}}}};
-    const K kern = table[lean ? 1 : 0][has_deg1 ? 1 : 0][vg ? 1 : 0][damp ? 1 : 0];
+    K kern = table[lean ? 1 : 0][has_deg1 ? 1 : 0][vg ? 1 : 0][damp ? 1 : 0];
+    // a thread owns one row for the whole launch: its column indices stay in registers (QLDPC_FLAG_WG_IDXLOAD keeps the per-iteration index loads)
+    if (lean && !vg && !damp && !A.edge_lanes && !(flags & QLDPC_FLAG_WG_IDXLOAD) && g->m <= block && g->max_row_deg <= 8 * kIdxChunks)
+        kern = has_deg1 ? minsum_wg_lean_kernel<true, false, false, true> : minsum_wg_lean_kernel<false, false, false, true>;
     if ((rcq = ensure_max_lds(g->device, reinterpret_cast<const void *>(kern), 160 * 1024)) != QLDPC_OK) return rcq;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, A);
     QLDPC_HIP_TRY(hipGetLastError());

@@ -98,7 +98,8 @@ def test_circuit_level_golden(L, golden, oracle, tag):
         for fl in (0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM):      # auto = workgroup-per-shot kernel; streaming kernel forced
             check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), fl), g, s)
         # the generic (any-input) workgroup kernel and the natural row / column order must agree with the lean, degree-sorted default
-        for fl in (L.FLAG_WG_GENERIC, L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC | L.FLAG_WG_ROWMAJOR, L.FLAG_WG_EDGE_LANES, L.FLAG_WG_EDGE_LANES | L.FLAG_FIXED_ITERS):
+        for fl in (L.FLAG_WG_GENERIC, L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC | L.FLAG_WG_ROWMAJOR, L.FLAG_WG_EDGE_LANES, L.FLAG_WG_EDGE_LANES | L.FLAG_FIXED_ITERS,
+                       L.FLAG_WG_IDXLOAD, L.FLAG_WG_IDXLOAD | L.FLAG_FIXED_ITERS):     # (default for m <= 1024: column indices resident in registers)
             check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), fl), g, s)
         rng = np.random.default_rng(5)                                 # ragged random batch, both kernels, vs the oracle
         synd = (rng.random((37, m)) < 0.1).astype(np.int8)
@@ -882,7 +883,7 @@ def test_random_irregular_graphs_all_kernels(L, oracle, monkeypatch):
             iters = int(rng.integers(1, 25))
             ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=iters, alpha=alpha, alpha_mode=mode, damping=damping, clip_llr=clip)
             variants = [(0, None), (L.FLAG_FIXED_ITERS, None), (L.FLAG_KERNEL_STREAM, None), (L.FLAG_WG_ROWMAJOR, None), (L.FLAG_WG_EDGE_LANES, None),
-                        (L.FLAG_WG_ROWMAJOR | L.FLAG_FIXED_ITERS, None)]
+                        (L.FLAG_WG_ROWMAJOR | L.FLAG_FIXED_ITERS, None), (L.FLAG_WG_IDXLOAD, None)]
             if n >= 2000:
                 variants.append((L.FLAG_WG_VGLOBAL, "1"))              # posteriors in global memory
                 variants.append((L.FLAG_WG_VGLOBAL | L.FLAG_WG_ROWMAJOR, "1"))
