@@ -265,6 +265,29 @@ __device__ __forceinline__ void wg_lean_row(const uint16_t *__restrict__ ec, int
     }
 }
 
+// the edges of one column of the variable pass when every lane of the wave has exactly D of them (column slots are handed out in degree order,
+// so that is the rule): D table loads, 2 D state reads, no predicate -- the 4-at-a-time loop below it runs three of every four columns of the
+// circuit-level matrices (degree 3, 5, 6, 2) through its predicated tail
+template <int D>
+__device__ __forceinline__ double wg_lean_col_edges(const uint32_t *__restrict__ ev, int n, const double2 *__restrict__ SP, const uint2 *__restrict__ SI) {
+    uint32_t e[D];
+    double2 pp[D];
+    uint2 si[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) e[u] = ev[(size_t)u * n];
+#pragma unroll
+    for (int u = 0; u < D; u++) { const uint32_t i = e[u] >> 8; pp[u] = SP[i]; si[u] = SI[i]; }
+    double s = 0.0;                                                                          // kernels.py:279
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const uint32_t k = e[u] & 255u;
+        const double mag = (k == (si[u].y >> 24)) ? pp[u].y : pp[u].x;
+        const uint32_t w = (k < 32u) ? (si[u].x >> k) : (si[u].y >> (k - 32u));
+        s += flip_sign(mag, w << 31);                                                        // kernels.py:316, ascending check order
+    }
+    return s;
+}
+
 template <bool NANSEL, bool VG, bool DAMP, bool RIDX = false>
 __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     extern __shared__ unsigned char lds[];
@@ -431,6 +454,19 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
                 const int j = A.col_of_slot[c], cdj = A.degc[c];
                 const double pr = A.prior_s[c];
                 double s = 0.0;                                                              // kernels.py:279
+                const int dmax = __builtin_amdgcn_readfirstlane(cdj);
+                if (dmax >= 2 && dmax <= 6 && __all(cdj == dmax)) {                          // the whole wave has one degree
+                    const uint32_t *ev = A.ell_var + c;
+                    switch (dmax) {
+                        case 2: s = wg_lean_col_edges<2>(ev, n, SP, SI); break;
+                        case 3: s = wg_lean_col_edges<3>(ev, n, SP, SI); break;
+                        case 4: s = wg_lean_col_edges<4>(ev, n, SP, SI); break;
+                        case 5: s = wg_lean_col_edges<5>(ev, n, SP, SI); break;
+                        default: s = wg_lean_col_edges<6>(ev, n, SP, SI); break;
+                    }
+                    V[j] = s + pr;                                                           // kernels.py:320
+                    continue;
+                }
                 for (int d0 = 0; d0 < cdj; d0 += 4) {                                        // (slots of one degree share a wave: no idle chunk)
                     uint32_t e[4];
                     double2 pp[4];
