@@ -676,7 +676,6 @@ struct OsdLdsArgs {
 #endif
 constexpr int kOsdBlock = QLDPC_OSD_BLOCK;      // columns resolved per block (4 per register of the resolving wave)
 static_assert(kOsdBlock <= 16, "one wave per column, at most 4 columns per wave with 256-thread blocks");
-__device__ __forceinline__ unsigned long long r_mask_word(const unsigned long long *R, int t, int mw, int w) { return R[t * mw + w]; }
 
 // Position-space formulation.  T (current rows = T * original rows, rows in their CURRENT physical order, i.e. after the
 // reference's swaps kernels.py:79-82) is kept as U = T^T: U[q] bit p = T[p][q].  Rows 0..m-1 of U belong to the original
@@ -962,11 +961,8 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                     }
                 };
                 if (!P.p3serial && nops > 0) {
-                    // Measured on the circuit-level matrices: 3.5 % of the (row, operation) pairs change the row, so a per-operation
-                    // "read two words, test, branch" is all latency.  Here a row reads the 2 + 16 words holding the positions the WHOLE
-                    // block tests back to back and keeps one bit per operation and kind (ab: bit a_k, pb: bit pp_k); the wave visits only
-                    // the operations some lane has a set bit for; a row that changes updates its later bits from opm / opx (wave 0 made
-                    // them after phase 2) instead of reading again.
+                    // rows in LDS: osd_rows_apply (osd_common.h) -- tested bits of the whole block read at once, only touched operations visited;
+                    // rows in HBM/L2 (UG): the same scheme written out below on the word-major transform
                     int ppv = opp[tid & 15], ptv = opt[tid & 15];           // operation k's (pp, column) sit in lane k of every 16
                     asm volatile("" : "+v"(ppv), "+v"(ptv));
                     const int ws = row >> 6, sh = row & 63;

@@ -11,6 +11,9 @@
 //   contiguous.  The syndrome test of iteration k is a by-product of the sweep of iteration k+1; a workgroup that
 //   converged fetches its next shot (persistent grid), so per-shot early exit costs nothing.
 // damping != 1 needs Q_old per edge (245 KB per shot): it lives in a slot-major HBM/L2 slab per workgroup (DAMP variants).
+// Round 2: rows and columns are handed to threads by SLOT in descending-degree order (a wave's rows / columns share a degree); where a
+// thread owns one row for the whole launch (m <= 1024) its column indices stay in registers (RIDX: no index loads in the check pass), and the
+// variable pass switches on the wave's column degree into a predicate-free body (wg_lean_col_edges).
 #include "common.h"
 #include "minsum_common.h"
 #include "osd_common.h"      // OSD_CLOCK / osd_timer_buffer: the diagnostic build (make timers) also times the phases of the lean kernel
