@@ -34,6 +34,7 @@ struct WgArgs {
     const uint32_t *ell_var;       // [cdeg][n] by column slot
     const double *prior_s;         // [n] prior by column slot
     const int32_t *indptr, *indices;   // CSR (rows by original index): the edge-lane check pass reads a row's columns as one coalesced run
+    int nan_deg1_only;             // host-verified: no column meets two degree-1 checks, so a NaN can only arise on the edge of a degree-1 check itself
     int edge_lanes;                // QLDPC_FLAG_WG_EDGE_LANES: 16 lanes per check with shuffle reductions (SURVEY 7-6 option B; measured slower)
     int64_t B;
     const int8_t *synd; const double *prior, *alpha;
@@ -193,11 +194,12 @@ __device__ __forceinline__ void wg_lean_chunk_cols(const uint32_t (&c)[8], int m
     }
     const uint32_t pw = (k0 < 32) ? (ip_lo >> k0) : (ip_hi >> (k0 - 32));                    // previous sign bits of this chunk
     const int au = argp - k0;
-    uint32_t cb = 0u;
+    uint32_t cb = 0u, pxw = 0u;
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         if (FULL || k0 + u < deg) {
-            par ^= (v[u] < 0.0);                                                             // kernels.py:349,356
+            // kernels.py:349,356.  A posterior is never -0.0 here; without degree-1 checks it is never NaN either, and v < 0 is its sign bit
+            if (NANSEL) par ^= (v[u] < 0.0); else pxw ^= (uint32_t)__double2hiint(v[u]);
             double x = v[u];
             if (!FIRST) {
                 const double mag = (u == au) ? p2s : p1s;                                    // kernels.py:313 (already carries the row sign)
@@ -215,6 +217,7 @@ __device__ __forceinline__ void wg_lean_chunk_cols(const uint32_t (&c)[8], int m
             min1 = wmin_abs2(min1, x);
         }
     }
+    par ^= (pxw >> 31) != 0u;
     if (k0 < 32) nlo |= cb << k0; else nhi |= cb << (k0 - 32);
 }
 
@@ -419,7 +422,14 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
                             const double2 t = SP[i]; const uint2 u = SI[i];
                             p1s = t.x; p2s = t.y; argp = (int)(u.y >> 24); ip_lo = u.x; ip_hi = u.y & 0x00FFFFFFu;
                         }
-                        if (RIDX) wg_lean_row_idx<NANSEL, false>(idx, m, V, deg, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, par, min1, min2, arg, nlo, nhi);
+                        if (RIDX) {
+                            // the NaN -> 0 test (kernels.py:328) is for the +-inf messages of degree-1 checks; when no column meets two of them
+                            // (host-verified) only the waves that hold such rows need it
+                            if (NANSEL && (!A.nan_deg1_only || __any(deg == 1)))
+                                wg_lean_row_idx<true, false>(idx, m, V, deg, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, par, min1, min2, arg, nlo, nhi);
+                            else
+                                wg_lean_row_idx<false, false>(idx, m, V, deg, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, par, min1, min2, arg, nlo, nhi);
+                        }
                         else
                         wg_lean_row<NANSEL, false, DAMP>(A.ell_col + i, m, V, deg, p1s, p2s, ip_lo, ip_hi, argp, clip, nclip, damping, one_minus_d,
                                                          DAMP ? Qo + i : nullptr, it < max_iter, par, min1, min2, arg, nlo, nhi);
@@ -566,6 +576,12 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     const size_t lds = wg_lds_bytes(g, vg, A.offP, A.offI, A.offF);
     bool has_deg1 = false;
     for (int i = 0; i < g->m; i++) has_deg1 = has_deg1 || (g->indptr[i + 1] - g->indptr[i] == 1);
+    A.nan_deg1_only = 1;
+    if (has_deg1) {
+        std::vector<uint8_t> hit(g->n, 0);
+        for (int i = 0; i < g->m && A.nan_deg1_only; i++)
+            if (g->indptr[i + 1] - g->indptr[i] == 1) { const int j = g->indices[g->indptr[i]]; if (hit[j]++) A.nan_deg1_only = 0; }
+    }
     const int block = (g->m > 512 || g->n > 4096) ? 1024 : 512;
     const unsigned grid = (unsigned)std::min<int64_t>(B, 256 * 2);
     int rcq = g->ws_queue.ensure(16);
