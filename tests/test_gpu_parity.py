@@ -897,6 +897,36 @@ def test_random_irregular_graphs_all_kernels(L, oracle, monkeypatch):
     assert ran["vg"] >= 6 and ran["stream"] >= 20
 
 
+def test_degree_one_checks_and_nan_posteriors(L, oracle):
+    """Degree-1 checks emit +-inf messages (kernels.py:301-314 with min2 = inf) and the next iteration turns inf - inf into 0 (kernels.py:328).
+    (a) every column meets at most one of them: only the waves that hold such rows run the NaN test; (b) a column meets TWO with opposite
+    syndromes: its posterior is NaN and every kernel must carry the NaN exactly like the reference.  Workgroup-per-shot kernels (register-
+    resident indices and the index-loading form), fixed-work and early exit, against the oracle."""
+    rng = np.random.default_rng(77)
+    m0, n = 700, 2600
+    rows = [np.sort(rng.choice(n, size=int(rng.integers(2, 20)), replace=False)) for _ in range(m0)]
+    for variant in ("one_each", "two_on_a_column"):
+        extra = [np.array([c]) for c in (5, 900, 1700)] if variant == "one_each" else [np.array([5]), np.array([5]), np.array([1700])]
+        allrows = extra[:1] + rows[:350] + extra[1:2] + rows[350:] + extra[2:]
+        ip = np.zeros(len(allrows) + 1, np.int32)
+        ip[1:] = np.cumsum([len(r) for r in allrows])
+        ix = np.concatenate(allrows).astype(np.int32)
+        graph = L.Graph(ip, ix, n)
+        m = len(allrows)
+        B = 6
+        E = (rng.random((B, n)) < 0.03).astype(np.int8)
+        synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+        synd[:, 0] = 1; synd[:, 351] = 0                                # the two degree-1 checks on column 5 disagree in variant (b)
+        prior = rng.normal(2.5, 1.0, n)
+        ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=9)
+        if variant == "two_on_a_column":
+            assert np.isnan(ref[2]).any()
+        for fl in (0, L.FLAG_FIXED_ITERS, L.FLAG_WG_IDXLOAD, L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC, L.FLAG_KERNEL_STREAM):
+            out = L.minsum_decode_batch(graph, synd, prior, 9, "dynamical", 1.0, flags=fl)
+            for name, a, b in zip(("err", "conv", "llr", "iter"), (out[0], out[1].astype(bool), out[2], out[3]), (ref[0], ref[1].astype(bool), ref[2], ref[3])):
+                assert np.array_equal(a, b, equal_nan=True), (variant, fl, name)
+
+
 def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
     """Differential sweep of OSD-0 over seeded random matrices (dependent rows, empty rows, heavy and empty columns, ties in |llr|,
     realisable and unrealisable syndromes) through its kernels: the one-wave literal elimination (small matrices), the row transform in LDS
