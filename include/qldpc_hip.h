@@ -159,9 +159,9 @@ int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t *syndromes, c
 int qldpc_osd0_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_syndromes, const double *d_llr, const int8_t *d_hard,
                          const int32_t *d_ordering, const int32_t *d_select, const int32_t *d_select_count, int flags, int8_t *d_solution,
                          void *stream);
-/* Phase counters of the OSD-0 kernels on the current device (uint64[16]; layout in csrc/osd_common.h).  Only the diagnostic build
+/* Phase counters of the OSD-0 kernels and of the workgroup BP kernel on the current device (uint64[32]; layout in csrc/osd_common.h).  Only the diagnostic build
  * (make -C csrc timers) counts; the product build carries no clock reads and returns QLDPC_ERR_UNSUPPORTED. */
-int qldpc_osd_timers_read(uint64_t *out16, int reset);
+int qldpc_osd_timers_read(uint64_t *out32, int reset);
 /* f1: performOSD_enhanced(H, syndrome, llr, hard, order, max_combinations) (src/decoding/osd.py:5-77), batched.  The OSD-0 solution is
  * returned whenever it reproduces the syndrome (osd.py:27-29); otherwise the <= C(order+10, <= order) flip sets over the least
  * reliable non-pivot positions are scored with recompute_solution / compute_metric (src/decoding/kernels.py:195-219) and the

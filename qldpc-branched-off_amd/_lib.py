@@ -302,8 +302,8 @@ def gf2_spmv_batch(graph, vectors):
 
 
 def osd_timers(reset=True):
-    """Phase counters of the OSD-0 kernels (diagnostic build only, see csrc/osd_common.h) -> uint64[16]."""
-    out = np.zeros(16, np.uint64)
+    """Phase counters of the OSD-0 kernels [0..15] and of the workgroup BP kernel [16..31] (diagnostic build only, see csrc/osd_common.h) -> uint64[32]."""
+    out = np.zeros(32, np.uint64)
     check(lib().qldpc_osd_timers_read(ptr(out, C.c_uint64), int(reset)))
     return out
 

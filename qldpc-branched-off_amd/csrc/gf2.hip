@@ -1223,8 +1223,8 @@ unsigned long long *osd_timer_buffer() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!d_buf[dev]) {
-        if (hipMalloc(reinterpret_cast<void **>(&d_buf[dev]), 16 * 8) != hipSuccess) { d_buf[dev] = nullptr; return nullptr; }
-        (void)hipMemset(d_buf[dev], 0, 16 * 8);
+        if (hipMalloc(reinterpret_cast<void **>(&d_buf[dev]), 32 * 8) != hipSuccess) { d_buf[dev] = nullptr; return nullptr; }
+        (void)hipMemset(d_buf[dev], 0, 32 * 8);
     }
     return d_buf[dev];
 #else
@@ -1233,14 +1233,15 @@ unsigned long long *osd_timer_buffer() {
 }
 }  // namespace qldpc
 
-// Phase counters of the OSD-0 kernels accumulated on the CURRENT device since the last reset (uint64[16], layout in osd_common.h).
+// Phase counters of the OSD-0 kernels ([0..15]) and of the workgroup BP kernel ([16..31]) accumulated on the CURRENT device since the last reset
+// (uint64[32], layout in osd_common.h).
 // Only the diagnostic build (make timers) counts; the default build returns QLDPC_ERR_UNSUPPORTED.  Synchronises the device.
 QLDPC_EXPORT int qldpc_osd_timers_read(uint64_t *out, int reset) {
     QLDPC_REQUIRE(out != nullptr, "out is NULL");
     unsigned long long *d = qldpc::osd_timer_buffer();
     if (!d) { qldpc::set_error("OSD phase timers are compiled out of this build (make -C csrc timers)"); return QLDPC_ERR_UNSUPPORTED; }
     QLDPC_HIP_TRY(hipDeviceSynchronize());
-    QLDPC_HIP_TRY(hipMemcpy(out, d, 16 * 8, hipMemcpyDeviceToHost));
-    if (reset) QLDPC_HIP_TRY(hipMemset(d, 0, 16 * 8));
+    QLDPC_HIP_TRY(hipMemcpy(out, d, 32 * 8, hipMemcpyDeviceToHost));
+    if (reset) QLDPC_HIP_TRY(hipMemset(d, 0, 32 * 8));
     return QLDPC_OK;
 }

@@ -525,8 +525,8 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
     }
 #ifdef QLDPC_OSD_TIMERS
     if (A.dbg && (tid & 63) == 0) {          // per-wave sums (the reader divides by the wave-iterations in [1])
-        atomicAdd(&A.dbg[1], n_it); atomicAdd(&A.dbg[2], (unsigned long long)t_chk); atomicAdd(&A.dbg[3], (unsigned long long)t_b1);
-        atomicAdd(&A.dbg[4], (unsigned long long)t_frz); atomicAdd(&A.dbg[5], (unsigned long long)t_var); atomicAdd(&A.dbg[6], (unsigned long long)t_b2);
+        atomicAdd(&A.dbg[17], n_it); atomicAdd(&A.dbg[18], (unsigned long long)t_chk); atomicAdd(&A.dbg[19], (unsigned long long)t_b1);      // slots 16.. : BP
+        atomicAdd(&A.dbg[20], (unsigned long long)t_frz); atomicAdd(&A.dbg[21], (unsigned long long)t_var); atomicAdd(&A.dbg[22], (unsigned long long)t_b2);
     }
 #endif
     clk_end(A.clk, clk0);

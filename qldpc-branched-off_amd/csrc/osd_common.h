@@ -5,7 +5,7 @@
 #include <stdint.h>
 
 // Phase timers of the OSD kernels exist only in the diagnostic build (`make timers` -> libqldpc_hip_timers.so, -DQLDPC_OSD_TIMERS);
-// the default build carries no clock reads.  Counters (uint64[16]): [0] shots, [1] chunks, [2] columns taken into blocks, [3] pivots,
+// the default build carries no clock reads.  Counters (uint64[32]; [16..22] belong to the workgroup BP kernel: wave-iterations, check pass, its barrier, freeze, variable pass, its barrier): [0] shots, [1] chunks, [2] columns taken into blocks, [3] pivots,
 // [4] cycles, [5] kill passes, [6] blocks, [8] sort, [9] phase 1 (reduce columns), [10] phase 2 (block pivots), [11] phase 3 (row updates),
 // [12] dependent-column tests, [13] back-substitution.
 #ifdef QLDPC_OSD_TIMERS

@@ -947,6 +947,8 @@ def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
         synd[B - 1] = rng.random(m) < 0.5
         synd[B - 2] = 0
         llr = rng.normal(1.0, 3.0, (B, n)); llr[0, : n // 3] = 1.25; llr[1] = np.round(llr[1])     # ties
+        llr[2, 0::2] = np.nextafter(1.5, 2.0); llr[2, 1::2] = 1.5          # keys that differ in the last mantissa bit only, against index order
+        llr[3, : n // 2] = -(1.0 + np.arange(n // 2)[::-1] * 2.0 ** -45)      # a long run of keys equal in their 40 high bits, descending
         hard = (rng.random((B, n)) < 0.1).astype(np.int8)
         want = np.stack([oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)])
         # (0 = the one-wave literal elimination for m <= 128, n <= 1024, else the transform kernel; FLAG_OSD_LDS forces the latter)

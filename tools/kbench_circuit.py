@@ -68,9 +68,9 @@ for rep in range(a.reps):
         print("  clock MHz (bp, osd):", plan.clock(), flush=True)
     if timers:
         h = _lib.osd_timers(reset=True).astype(float)
-        if not h[0] and h[1]:
-            print(f"  [bp timers] wave-iterations={h[1]:.0f}; cycles per iteration (mean over waves): check {h[2] / h[1]:.0f} + barrier {h[3] / h[1]:.0f} + freeze {h[4] / h[1]:.0f} "
-                  f"+ variable {h[5] / h[1]:.0f} + barrier {h[6] / h[1]:.0f}", flush=True)
+        if h[17]:
+            print(f"  [bp timers] wave-iterations={h[17]:.0f}; cycles per iteration (mean over waves): check {h[18] / h[17]:.0f} + barrier {h[19] / h[17]:.0f} + freeze {h[20] / h[17]:.0f} "
+                  f"+ variable {h[21] / h[17]:.0f} + barrier {h[22] / h[17]:.0f}", flush=True)
         if h[0]:
             print(f"  [osd timers] shots={h[0]:.0f} chunks/shot={h[1] / h[0]:.2f} cols/shot={h[2] / h[0]:.1f} pivots/shot={h[3] / h[0]:.1f} kills/shot={h[5] / h[0]:.1f} "
                   f"blocks/shot={h[6] / h[0]:.1f} kcycles/shot={h[4] / h[0] / 1e3:.1f} (sort {h[8] / h[0] / 1e3:.0f} p1 {h[9] / h[0] / 1e3:.0f} p2 {h[10] / h[0] / 1e3:.0f} "
