@@ -101,6 +101,13 @@ const char *qldpc_last_error(void);
 int qldpc_version(void);
 /* number of usable HIP devices (0 when none; never fails) */
 int qldpc_device_count(void);
+/* Process-wide kernel-selection switches for tools/ and the parity tests.  Results never depend on them (every selectable kernel is
+ * checked against the same fixtures); the defaults are what bench.py measures.  New here (the reference has no counterpart).
+ *   "regular_kernel"  code-capacity decoder for (6,3)-regular graphs: 0 = automatic, 1 = 72-thread teams with workgroup barriers
+ *                     (csrc/minsum_regular.hip), 2 = wave-private teams, no barrier (csrc/minsum_wave.hip) where the inputs allow it
+ *   "wave_cpl" / "wave_rst" / "wave_grid"  shape of the wave-private kernel: checks per lane (0 = automatic, 4, 5, 6, 9), row stride of
+ *                     its message buffer in doubles (0, 6, 7), waves per CU of its persistent grid (0 .. 32) */
+int qldpc_set_option(const char *name, int value);
 
 /* Build a Tanner-graph handle on `device`.  Validates the CSR (monotone indptr, 0 <= col < n, strictly
  * increasing columns per row) and derives the CSC view with per-column ASCENDING check order, which is what

@@ -55,6 +55,8 @@ def _ctype_of(decl):
     base = base[0] if len(base) == 1 else (base[0] if base[0] in _SCALARS or base[0].startswith("qldpc_") or base[0] in ("void", "char") else base[-2])
     if stars == 0:
         return _SCALARS[base]
+    if base == "char" and stars == 1:
+        return C.c_char_p              # NUL-terminated name
     if base == "qldpc_circuit_desc":
         t = CircuitDesc
     elif base in ("void", "char") or base.startswith("qldpc_"):
@@ -131,6 +133,11 @@ def check(rc):
 
 def device_count():
     return int(lib().qldpc_device_count())
+
+
+def set_option(name, value):
+    """Process-wide kernel-selection switch (include/qldpc_hip.h: qldpc_set_option); results never depend on it."""
+    check(lib().qldpc_set_option(name.encode(), int(value)))
 
 
 def require_device():

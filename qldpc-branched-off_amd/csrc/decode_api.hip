@@ -38,8 +38,12 @@ static int dispatch_kernel(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     const bool want_stream = flags & QLDPC_FLAG_KERNEL_STREAM;
     const bool want_res = flags & (QLDPC_FLAG_KERNEL_RESIDENT | QLDPC_FLAG_KERNEL_GENERIC);
     const bool can_res = resident_supported(g, damping);
-    if (!want_stream && !(flags & QLDPC_FLAG_KERNEL_GENERIC) && regular_supported(g, clip, max_iter))
+    if (!want_stream && !(flags & QLDPC_FLAG_KERNEL_GENERIC) && regular_supported(g, clip, max_iter)) {
+        const bool clean = nanfree && (flags & QLDPC_FLAG_INTERNAL_PRIOR_LE_CLIP);
+        if (wave_kernel_choice() == 2 && wave_supported(g, damping, clean))
+            return minsum_wave_launch(g, B, d_synd, d_prior, max_iter, d_alpha, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
         return minsum_regular_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
+    }
     if (want_res && !can_res) {
         set_error("resident kernel does not support this graph (m=%d n=%d max row degree %d, max column degree %d)", g->m, g->n,
                   g->max_row_deg, g->max_col_deg);
@@ -83,7 +87,7 @@ static int check_decode_args(const qldpc_graph *g, int64_t B, const void *synd, 
 
 static int decode_dev_impl(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior,
                                                int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq,
-                                               int alpha_len, double damping, double clip_llr, int flags, bool prior_finite, int8_t *d_err,
+                                               int alpha_len, double damping, double clip_llr, int flags, bool prior_finite, bool prior_le_clip, int8_t *d_err,
                                                double *d_llr, uint8_t *d_conv, int32_t *d_iter, void *stream) {
     int rc = check_decode_args(g, B, d_synd, d_prior, max_iter, clip_llr, d_err, d_llr, d_conv, d_iter);
     if (rc != QLDPC_OK) return rc;
@@ -97,7 +101,8 @@ static int decode_dev_impl(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     if ((rc = g->alpha_table(tab, s, &d_alpha)) != QLDPC_OK) return rc;
     // prior_finite here means "host-verified clean prior" (finite, no -0.0); clip and alphas are checked the same way
     bool nanfree = prior_finite && std::isfinite(damping) && inputs_clean(nullptr, 0, clip_llr, tab.data(), max_iter);
-    flags = (flags & QLDPC_FLAG_PUBLIC_MASK) | (prior_finite ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0);
+    flags = (flags & QLDPC_FLAG_PUBLIC_MASK) | (prior_finite ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0) |
+            ((prior_finite && prior_le_clip) ? QLDPC_FLAG_INTERNAL_PRIOR_LE_CLIP : 0);
     return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip_llr, flags, nanfree, d_err,
                                   d_llr, d_conv, d_iter, s);
 }
@@ -107,7 +112,7 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch_dev(const qldpc_graph *g, int64_t B, 
                                                int alpha_len, double damping, double clip_llr, int flags, int8_t *d_err,
                                                double *d_llr, uint8_t *d_conv, int32_t *d_iter, void *stream) {
     // the prior lives on the device: its finiteness is unknown here, so the NaN test of kernels.py:328 stays in
-    return decode_dev_impl(g, B, d_synd, d_prior, max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, damping, clip_llr, flags, false,
+    return decode_dev_impl(g, B, d_synd, d_prior, max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, damping, clip_llr, flags, false, false,
                            d_err, d_llr, d_conv, d_iter, stream);
 }
 
@@ -134,8 +139,10 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, cons
     if (n) QLDPC_HIP_TRY(hipMemcpyAsync(base + o_prior, prior, n * 8, hipMemcpyHostToDevice, nullptr));
     const double one = 1.0;
     const bool prior_finite = inputs_clean(prior, (int)n, 1.0, &one, 1);
+    bool prior_le_clip = prior_finite;
+    for (size_t j = 0; j < n && prior_le_clip; j++) prior_le_clip = std::fabs(prior[j]) <= clip_llr;
     rc = decode_dev_impl(g, B, reinterpret_cast<int8_t *>(base + o_synd), reinterpret_cast<double *>(base + o_prior), max_iter, alpha_mode,
-                         alpha_val, alpha_seq, alpha_len, damping, clip_llr, flags, prior_finite, reinterpret_cast<int8_t *>(base + o_err),
+                         alpha_val, alpha_seq, alpha_len, damping, clip_llr, flags, prior_finite, prior_le_clip, reinterpret_cast<int8_t *>(base + o_err),
                          reinterpret_cast<double *>(base + o_llr), reinterpret_cast<uint8_t *>(base + o_conv),
                          reinterpret_cast<int32_t *>(base + o_iter), nullptr);
     if (rc != QLDPC_OK) return rc;

@@ -122,7 +122,7 @@ struct qldpc_cc_plan {
     int64_t batch = 0;
     std::vector<double> alpha;
     DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol, d_cold, d_clk;
-    bool fused = false, nanfree = false;
+    bool fused = false, nanfree = false, clean = false;      // clean: nanfree and |prior| <= clip (what the wave-private kernel needs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decode-kernel brackets not yet read
     std::vector<hipEvent_t> pool;
@@ -165,6 +165,7 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
     {
         const double pr = std::log((1.0 - p) / p);
         P->nanfree = inputs_clean(&pr, 1, clip_llr, P->alpha.data(), max_iter);
+        P->clean = P->nanfree && std::fabs(pr) <= clip_llr;
     }
     P->fused = !(flags & (QLDPC_FLAG_MC_UNFUSED | QLDPC_FLAG_KERNEL_STREAM | QLDPC_FLAG_KERNEL_GENERIC)) && damping == 1.0 &&
                regular_supported(g, clip_llr, max_iter);
@@ -212,8 +213,12 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
             QLDPC_HIP_TRY(hipMemsetAsync(P->d_count.p, 0, 4, s));
             hipEvent_t e0 = get_event(P), e1 = get_event(P);
             if (e0 && e1) QLDPC_HIP_TRY(hipEventRecord(e0, s));
-            rc = mc_regular_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, P->nanfree, seed,
-                                   shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_cold.p, s);
+            if (wave_kernel_choice() == 2 && wave_supported(g, P->damping, P->clean))
+                rc = mc_wave_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, seed, shot_begin + off,
+                                    P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_cold.p, s);
+            else
+                rc = mc_regular_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, P->nanfree, seed,
+                                       shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_cold.p, s);
             if (rc != QLDPC_OK) return rc;
             if (e0 && e1) { QLDPC_HIP_TRY(hipEventRecord(e1, s)); P->pending.emplace_back(e0, e1); }
             if (P->use_osd) {
@@ -238,7 +243,7 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
         {
             std::lock_guard<std::mutex> lk(g->mu);
             rc = minsum_decode_dispatch(g, B, P->d_synd.as<int8_t>(), P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(),
-                                        P->damping, P->clip, (P->flags & QLDPC_FLAG_PUBLIC_MASK) | (P->nanfree ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0), P->nanfree, P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
+                                        P->damping, P->clip, (P->flags & QLDPC_FLAG_PUBLIC_MASK) | (P->nanfree ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0) | (P->clean ? QLDPC_FLAG_INTERNAL_PRIOR_LE_CLIP : 0), P->nanfree, P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
                                         P->d_conv.as<uint8_t>(), P->d_iter.as<int32_t>(), s);
         }
         if (rc != QLDPC_OK) return rc;

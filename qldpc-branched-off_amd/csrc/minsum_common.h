@@ -25,6 +25,7 @@ __device__ __forceinline__ bool prior_not_finite(double p) { return !(fabs(p) < 
 // internal flag (upper half of `flags`): the caller verified on the host that every prior is finite
 #define QLDPC_FLAG_PUBLIC_MASK 0x0FFFFFFF          // flag bits callers may set (include/qldpc_hip.h)
 #define QLDPC_FLAG_INTERNAL_PRIOR_FINITE 0x40000000
+#define QLDPC_FLAG_INTERNAL_PRIOR_LE_CLIP 0x20000000   // ... and every |prior| <= clip (iteration 0 then needs no unclipped special case)
 
 // reference src/decoding/kernels.py:339-342
 __device__ __forceinline__ double clip_only(double q, double clip) {
@@ -55,6 +56,13 @@ int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_f
 size_t mc_regular_cold_bytes();
 int judge_failed_launch(const qldpc_graph *g, const int32_t *d_count, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
                         const int8_t *f_dec, unsigned long long *d_tally, hipStream_t stream);
+// wave-private kernel for (6,3)-regular graphs and clean inputs (minsum_wave.hip); option "regular_kernel" selects between the two
+bool wave_supported(const qldpc_graph *g, double damping, bool clean);
+int wave_kernel_choice();     // 0 automatic, 1 team kernel, 2 wave kernel (qldpc_set_option)
+int minsum_wave_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
+                       double clip, int flags, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
+int mc_wave_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int max_iter, const double *d_alpha, double clip, int flags,
+                   uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask, void *d_cold, hipStream_t stream);
 // workgroup-per-shot kernel for large graphs (minsum_wg.hip)
 bool wg_supported(const qldpc_graph *g, double damping);
 int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
