@@ -122,6 +122,10 @@ struct qldpc_cc_plan {
     int64_t batch = 0;
     std::vector<double> alpha;
     DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol, d_cold, d_clk;
+    DevBuf d_lptr, d_lidx, d_cont;        // logical rows in CSR form and the list of shots the bit-sliced first iteration hands on (mc_first.hip)
+    bool clk_first = false;               // the last launch stamped the first-iteration kernel's probe buffer
+    bool first_ok = false;                // the closed form of iteration 0 applies to this plan (uniform prior > 0, column degree <= 3, ...)
+    unsigned negbits = 0;
     bool fused = false, nanfree = false, clean = false;      // clean: nanfree and |prior| <= clip (what the wave-private kernel needs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decode-kernel brackets not yet read
@@ -182,11 +186,29 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
         set_error("plan upload failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(QLDPC_ERR_HIP);
     }
+    if (P->fused && !(flags & QLDPC_FLAG_FIXED_ITERS) && max_iter >= 1 && P->clean) {
+        P->first_ok = mc_first_table(g, prior[0], P->alpha[0], clip_llr, max_iter, P->negbits) && (size_t)(g->m + g->n) * 64 <= 60 * 1024;
+        if (P->first_ok) {
+            std::vector<int32_t> lptr(k + 1, 0), lidx;
+            for (int r = 0; r < k; r++) {
+                for (size_t j = 0; j < n; j++) if (L[(size_t)r * n + j] & 1) lidx.push_back((int32_t)j);
+                lptr[r + 1] = (int32_t)lidx.size();
+            }
+            if ((rc = P->d_lptr.ensure(lptr.size() * 4)) || (rc = P->d_lidx.ensure(std::max<size_t>(lidx.size(), 1) * 4)) || (rc = P->d_cont.ensure(batch * 4)))
+                return fail(rc);
+            if (hipMemcpy(P->d_lptr.p, lptr.data(), lptr.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                (!lidx.empty() && hipMemcpy(P->d_lidx.p, lidx.data(), lidx.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+                set_error("plan upload failed: %s", hipGetErrorString(hipGetLastError()));
+                return fail(QLDPC_ERR_HIP);
+            }
+        }
+    }
     if (P->fused) {
         if ((rc = P->d_cold.ensure(mc_regular_cold_bytes())) != QLDPC_OK) return fail(rc);
         if (flags & QLDPC_FLAG_CLOCK_PROBE) {
-            if ((rc = P->d_clk.ensure(2 * kClkSlots * 8)) != QLDPC_OK) return fail(rc);
-            if (hipMemset(P->d_clk.p, 0, 2 * kClkSlots * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
+            // two probe buffers: [0] the full decoder's workgroups, [1] the first-iteration kernel's
+            if ((rc = P->d_clk.ensure(4 * kClkSlots * 8)) != QLDPC_OK) return fail(rc);
+            if (hipMemset(P->d_clk.p, 0, 4 * kClkSlots * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
         }
         if ((rc = mc_regular_fill_cold(P->d_cold.p, P->d_tally.as<unsigned long long>(), P->d_count.as<int32_t>(), P->d_list.as<int32_t>(),
                                        P->d_synd.as<int8_t>(), P->d_err.as<int8_t>(), P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
@@ -210,10 +232,20 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
         if (P->fused) {
             // one launch: sample -> syndrome -> decode -> logical compare -> tally; BP failures are exported for OSD-0.
             // The failure records reuse the per-shot buffers of the unfused path (synd/err/dec/llr), compacted.
-            QLDPC_HIP_TRY(hipMemsetAsync(P->d_count.p, 0, 4, s));
+            QLDPC_HIP_TRY(hipMemsetAsync(P->d_count.p, 0, 16, s));          // [0] BP failures (OSD-0 list), [2] shots handed on by the first iteration
             hipEvent_t e0 = get_event(P), e1 = get_event(P);
             if (e0 && e1) QLDPC_HIP_TRY(hipEventRecord(e0, s));
-            if (wave_kernel_choice() == 2 && wave_supported(g, P->damping, P->clean))
+            if (P->first_ok && mc_first_choice() == 1 && wave_kernel_choice() != 2) {
+                // reference semantics: every shot through the bit-sliced first iteration, the few that do not stop there through the full decoder
+                unsigned long long *clk = (P->flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() + 2 * kClkSlots : nullptr;
+                P->clk_first = true;
+                if ((rc = mc_first_launch(g, P->k, P->d_lptr.as<int32_t>(), P->d_lidx.as<int32_t>(), B, seed, shot_begin + off, P->thr, P->negbits,
+                                          P->d_tally.as<unsigned long long>(), P->d_cont.as<int32_t>(), P->d_count.as<int32_t>() + 2, clk, s)) != QLDPC_OK)
+                    return rc;
+                rc = mc_regular_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags & ~QLDPC_FLAG_CLOCK_PROBE, P->nanfree, seed,
+                                       shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_cold.p, s, P->d_cont.as<int32_t>(),
+                                       P->d_count.as<int32_t>() + 2);
+            } else if ((P->clk_first = false), wave_kernel_choice() == 2 && wave_supported(g, P->damping, P->clean))
                 rc = mc_wave_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, seed, shot_begin + off,
                                     P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_cold.p, s);
             else
@@ -309,7 +341,7 @@ QLDPC_EXPORT int qldpc_cc_plan_clock(qldpc_cc_plan *P, void *stream, double *mhz
     QLDPC_USE_DEVICE(P->g->device);
     QLDPC_HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
     std::vector<unsigned long long> h(2 * kClkSlots);
-    QLDPC_HIP_TRY(hipMemcpy(h.data(), P->d_clk.p, h.size() * 8, hipMemcpyDeviceToHost));
+    QLDPC_HIP_TRY(hipMemcpy(h.data(), P->d_clk.as<unsigned long long>() + (P->clk_first ? 2 * kClkSlots : 0), h.size() * 8, hipMemcpyDeviceToHost));
     *mhz = clock_probe_median(h.data(), kClkSlots);
     return QLDPC_OK;
 }
@@ -320,7 +352,7 @@ QLDPC_EXPORT void qldpc_cc_plan_destroy(qldpc_cc_plan *P) {
     for (auto &pr : P->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : P->pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&P->d_alpha, &P->d_prior, &P->d_Lmask, &P->d_err, &P->d_synd, &P->d_dec, &P->d_llr, &P->d_conv, &P->d_iter,
-                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol, &P->d_cold, &P->d_clk})
+                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol, &P->d_cold, &P->d_clk, &P->d_lptr, &P->d_lidx, &P->d_cont})
         b->release();
     delete P;
 }

@@ -50,7 +50,13 @@ int minsum_regular_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd,
                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
 int mc_regular_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int max_iter, const double *d_alpha, double clip, int flags,
                       bool nanfree, uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask,
-                      void *d_cold, hipStream_t stream);
+                      void *d_cold, hipStream_t stream, const int32_t *d_shot_list = nullptr, const int32_t *d_shot_count = nullptr);
+// bit-sliced first iteration of a uniform-prior Monte-Carlo plan under reference semantics (mc_first.hip)
+bool mc_first_table(const qldpc_graph *g, double p0, double alpha0, double clip, int max_iter, unsigned &negbits);
+int mc_first_launch(const qldpc_graph *g, int k, const int32_t *d_lptr, const int32_t *d_lidx, int64_t B, uint64_t seed, int64_t shot_begin, uint32_t thr,
+                    unsigned negbits, unsigned long long *d_tally, int32_t *d_cont_list, int32_t *d_cont_count, unsigned long long *d_clk, hipStream_t stream);
+void mc_first_set_bits(int bits);
+int mc_first_choice();       // qldpc_set_option("mc_first_iteration"): 1 = use it where it applies (default), 0 = full decoder for every shot
 int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd,
                          int8_t *f_err, int8_t *f_hard, double *f_llr, unsigned long long *d_clk);
 size_t mc_regular_cold_bytes();

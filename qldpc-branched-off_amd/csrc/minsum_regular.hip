@@ -36,6 +36,7 @@ struct RegArgs {
     uint32_t seed_lo, seed_hi, thr; int use_osd;
     int64_t shot_begin;
     const uint64_t *Lmask;
+    const int32_t *shot_list, *shot_count;   // Monte-Carlo mode: decode only the listed shots (offsets from shot_begin; device-resident count), else NULL
     const struct RegCold *cold;     // rarely used pointers live in device memory to keep scalar registers free
     // LDS carve (byte offsets)
     int offV, offE, offL, offI, offA, offT;
@@ -103,14 +104,16 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
         }
     }
 
-    for (int64_t base = (int64_t)blockIdx.x * S; base < A.B; base += (int64_t)gridDim.x * S) {
+    // a shot list (the shots the bit-sliced first iteration, mc_first.hip, did not finish) replaces the contiguous range
+    const int64_t nshots = (MC && A.shot_list) ? (int64_t)*A.shot_count : A.B;
+    for (int64_t base = (int64_t)blockIdx.x * S; base < nshots; base += (int64_t)gridDim.x * S) {
         const int64_t b = base + slot;
-        const bool valid = in_team && b < A.B;
+        const bool valid = in_team && b < nshots;
         bool csyn = false;
         if (MC) {
             // ---- sample e ~ Bernoulli(p)^n (4 bits per Philox block), s = H e ----
             if (valid && member < nq) {
-                const uint64_t g = (uint64_t)(A.shot_begin + b);
+                const uint64_t g = (uint64_t)(A.shot_begin + (A.shot_list ? (int64_t)A.shot_list[b] : b));
                 uint32_t o[4];
                 philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)member, 0u, A.seed_lo, A.seed_hi, o);
                 uint32_t w = 0;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
 #pragma unroll
         for (int v = 0; v < 2; v++) if (has_var[v]) Vl[vj[v]] = vprior[v];             // Q_{-1} = prior[col] (kernels.py:263-265)
         if (in_team && member == 0) { unsat[0] = 0; unsat[1] = 0; }
-        if (threadIdx.x == 0) { const int64_t left = A.B - base; active[0] = (int)(left < S ? left : S); }
+        if (threadIdx.x == 0) { const int64_t left = nshots - base; active[0] = (int)(left < S ? left : S); }
         bool done = !valid;
         __syncthreads();
 
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
                 }
                 __syncthreads();
             }
-            if ((int)threadIdx.x < S && base + threadIdx.x < A.B) {
+            if ((int)threadIdx.x < S && base + threadIdx.x < nshots) {
                 const int *r = I + 2 * S + 2 + 4 * threadIdx.x;
                 const unsigned long long lm = *(reinterpret_cast<unsigned long long *>(lds + A.offL) + threadIdx.x);
                 const bool exported = (r[0] == 0) && A.use_osd;
@@ -449,14 +452,17 @@ int minsum_regular_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd,
 
 int mc_regular_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int max_iter, const double *d_alpha, double clip, int flags,
                       bool nanfree, uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask,
-                      void *d_cold, hipStream_t stream) {
+                      void *d_cold, hipStream_t stream, const int32_t *d_shot_list, const int32_t *d_shot_count) {
     RegPlan P;
     if (!plan_regular(g, max_iter, P)) { set_error("graph is not regular (6,3)/(4,2)/(8,4)"); return QLDPC_ERR_UNSUPPORTED; }
     RegArgs A;
     fill_common(g, P, A, B, d_prior, max_iter, d_alpha, 1.0, clip, flags);
     A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32); A.thr = thr; A.use_osd = use_osd; A.shot_begin = shot_begin;
     A.Lmask = d_Lmask; A.cold = reinterpret_cast<const RegCold *>(d_cold);
-    return dispatch_reg<true>(P, A, false, nanfree, persistent_grid(B, P.S), stream);
+    A.shot_list = d_shot_list; A.shot_count = d_shot_count;
+    // listed shots: a few percent of the batch at BASELINE's error rates -- a grid for B / 16 shots covers them in one or two rounds
+    const unsigned grid = d_shot_list ? persistent_grid(std::max<int64_t>(B / 16, 1), P.S) : persistent_grid(B, P.S);
+    return dispatch_reg<true>(P, A, false, nanfree, grid, stream);
 }
 
 // Fills the device-resident cold-argument block of a Monte-Carlo plan (done once per plan).

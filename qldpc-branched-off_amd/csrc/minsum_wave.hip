@@ -451,7 +451,8 @@ __global__ __launch_bounds__(64, (CPL > 6) ? 1 : 2) void minsum_wave_kernel(Wave
 }
 
 // ------------------------------------------------------------------------------------------ host side
-static std::atomic<int> g_opt_kernel{0}, g_opt_cpl{0}, g_opt_rst{0}, g_opt_grid{0};
+static std::atomic<int> g_opt_kernel{0}, g_opt_cpl{0}, g_opt_rst{0}, g_opt_grid{0}, g_opt_first{1};
+int mc_first_choice() { return g_opt_first.load(); }
 
 struct WavePlan { int cpl, vb, rst, LPS, SPW, team_bytes, offV, offM; size_t lds; int waves_per_cu; };
 
@@ -569,6 +570,8 @@ QLDPC_EXPORT int qldpc_set_option(const char *name, int value) {
     if (!std::strcmp(name, "wave_cpl")) { QLDPC_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6 || value == 9, "wave_cpl: 0, 4, 5, 6 or 9"); qldpc::g_opt_cpl = value; return QLDPC_OK; }
     if (!std::strcmp(name, "wave_rst")) { QLDPC_REQUIRE(value == 0 || value == 6 || value == 7, "wave_rst: 0, 6 or 7"); qldpc::g_opt_rst = value; return QLDPC_OK; }
     if (!std::strcmp(name, "wave_grid")) { QLDPC_REQUIRE(value >= 0 && value <= 32, "wave_grid: 0 .. 32"); qldpc::g_opt_grid = value; return QLDPC_OK; }
+    if (!std::strcmp(name, "mc_first_iteration")) { QLDPC_REQUIRE(value == 0 || value == 1, "mc_first_iteration: 0 or 1"); qldpc::g_opt_first = value; return QLDPC_OK; }
+    if (!std::strcmp(name, "mc_first_bits")) { QLDPC_REQUIRE(value == 8 || value == 16 || value == 32, "mc_first_bits: 8, 16 or 32"); qldpc::mc_first_set_bits(value); return QLDPC_OK; }
     qldpc::set_error("unknown option '%s'", name);
     return QLDPC_ERR_INVALID;
 }

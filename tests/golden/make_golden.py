@@ -415,25 +415,35 @@ def prior_llrs(probs):
         return np.clip(np.nan_to_num(np.log((1 - probs) / probs)), -50, 50)
 
 
-def gen_circuit_decode(tag, noise, ndec, n_osd, max_iter):
-    """a1 on the circuit-level graphs + a9 OSD-0 (and the np.argsort order it used) + a15 priors."""
+def gen_circuit_decode(tag, noise, ndec, n_osd, max_iter, extra=0):
+    """a1 on the circuit-level graphs + a9 OSD-0 (and the np.argsort order it used) + a15 priors.
+    `extra` more syndrome pairs come from further run_trial_fast draws at p = 0.005 (seeds 9500 + t; only the syndromes are kept)."""
     path, code, cycles, _ = CACHE[tag]
     m = np.load(os.path.join(REF, path))
     out = {}
     sel = [i for i in range(len(noise["error_rates"])) if noise["error_rates"][i] == 0.005][:ndec]
+    more = {"sparse_z": [], "sparse_x": []}
+    if extra:
+        d, cb, comp = build_circuit(tag)
+        for t in range(extra):
+            np.random.seed(9500 + t)
+            a_, b_, c_, d_ = run_trial_fast(comp, 0.005, d["Lx"], d["Lz"])
+            more["sparse_z"].append(np.asarray(a_, np.int8)); more["sparse_x"].append(np.asarray(c_, np.int8))
     for s, spk in (("Z", "sparse_z"), ("X", "sparse_x")):
         Hd = m[f"Hdec{s}"]
         Hc = csr_of(Hd)
         llr = prior_llrs(m[f"channel_probs{s}"])
         out[f"llrs_{s}"] = llr
         synds = noise[spk][sel]
+        if extra:
+            synds = np.concatenate([synds, np.array(more[spk], np.int8)])
         t0 = time.time()
         E, C, V, I = batch_sparse(Hc, synds, llr, maxIter=max_iter, alpha=1.0, alpha_mode="dynamical")
-        print(f"    {tag} {s}: {len(sel)} decodes in {time.time() - t0:.1f}s conv={C.tolist()} iters={I.tolist()}")
+        print(f"    {tag} {s}: {len(synds)} decodes in {time.time() - t0:.1f}s conv={C.tolist()} iters={I.tolist()}")
         out[f"{s}_syndromes"] = synds.astype(np.int8)
         out[f"{s}_err"], out[f"{s}_conv"], out[f"{s}_llr"], out[f"{s}_iter"] = E, C, V, I
         # OSD-0 on the first n_osd non-converged decodes (reference call: engine.py:96-97, osd.py:5-29)
-        fails = [i for i in range(len(sel)) if not C[i]][:n_osd]
+        fails = [i for i in range(len(synds)) if not C[i]][:n_osd]
         Hf = np.asarray(Hd, dtype=np.float64)
         sols, orders = [], []
         real_argsort = np.argsort
@@ -648,7 +658,8 @@ def main():
     if "circ72" in todo:
         print("[circ72]"); nz = gen_noise("circ72", 8); gen_circuit_decode("circ72", nz, 4, 3, 50)
     if "circ144" in todo:
-        print("[circ144]"); nz = gen_noise("circ144", 4); gen_circuit_decode("circ144", nz, 2, 1, 50)
+        # SURVEY 8c counts at production size: 8 draws per error rate, 16 syndromes and 8 reference OSD-0 solutions per sector
+        print("[circ144]"); nz = gen_noise("circ144", 16); gen_circuit_decode("circ144", nz, 8, 8, 50, extra=8)
     if "estimators" in todo:
         print("[estimators]"); gen_estimators()
     if "osdw" in todo:

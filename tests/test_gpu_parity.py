@@ -331,6 +331,92 @@ def test_code_capacity_tally_matches_oracle(L, oracle):
     assert ref[0] == 1000
 
 
+@pytest.fixture
+def options(L):
+    """qldpc_set_option switches are process-wide: put the defaults back after a test that turns them"""
+    yield L.set_option
+    for name, v in (("regular_kernel", 0), ("wave_cpl", 0), ("wave_rst", 0), ("wave_grid", 0), ("mc_first_iteration", 1), ("mc_first_bits", 8)):
+        L.set_option(name, v)
+
+
+def test_first_iteration_pipeline_equals_full_decoder_and_oracle(L, oracle, options):
+    """Reference semantics through the bit-sliced first iteration (csrc/mc_first.hip) + the full decoder on the shots it lists
+    == the full decoder on every shot == the oracle: identical tallies for every code, error rate, iteration cap and ragged batch."""
+    from qldpc_amd.data import load_code
+    for tag in ("bb72", "bb144", "bb288", "bb90"):
+        c = load_code(tag)
+        ip, ix, n = c["Hx_indptr"], c["Hx_indices"], c["n"]
+        graph = L.Graph(ip, ix, n)
+        for p, mi, count, begin, osd in ((0.005, 50, 20011, 12345, True), (0.03, 50, 9000, 7, True), (0.08, 7, 5003, 0, True), (0.005, 1, 8000, 99, True),
+                                         (0.02, 2, 6000, 5, False), (0.3, 30, 700, 1, True), (0.01, 50, 1, 3, True), (0.01, 50, 511, 3, True)):
+            ref = oracle.cc_sample_decode_tally(ip, ix, n, c["Lx"], p, 4242, begin, count, max_iter=mi, use_osd=osd, threads=0)
+            options("mc_first_iteration", 0)
+            full = L.cc_sample_decode_tally(graph, c["Lx"], p, 4242, begin, count, max_iter=mi, use_osd=osd)
+            assert np.array_equal(full, ref), (tag, p, mi, full.tolist(), ref.tolist())
+            options("mc_first_iteration", 1)
+            for bits in (8, 16, 32):
+                options("mc_first_bits", bits)
+                got = L.cc_sample_decode_tally(graph, c["Lx"], p, 4242, begin, count, max_iter=mi, use_osd=osd)
+                assert np.array_equal(got, ref), (tag, p, mi, bits, got.tolist(), ref.tolist())
+    # a plan over several batches, the last one ragged; and a code the shortcut does not apply to (Steane: irregular -> unfused pipeline)
+    c = load_code("bb144")
+    graph = L.Graph(c["Hx_indptr"], c["Hx_indices"], c["n"])
+    ref = oracle.cc_sample_decode_tally(c["Hx_indptr"], c["Hx_indices"], c["n"], c["Lx"], 0.01, 5, 100, 10000, max_iter=50, threads=0)
+    plan = L.CodeCapacityPlan(graph, c["Lx"], 0.01, max_iter=50, batch=4096)
+    plan.run(5, 100, 10000)
+    assert np.array_equal(plan.read(), ref)
+    plan.close()
+    c = load_code("steane")
+    graph = L.Graph(c["Hx_indptr"], c["Hx_indices"], c["n"])
+    ref = oracle.cc_sample_decode_tally(c["Hx_indptr"], c["Hx_indices"], c["n"], c["Lx"], 0.05, 5, 0, 3000, max_iter=50, threads=0)
+    assert np.array_equal(L.cc_sample_decode_tally(graph, c["Lx"], 0.05, 5, 0, 3000, max_iter=50), ref)
+
+
+def test_wave_private_kernel_matches_golden_and_team_kernel(L, golden, oracle, options):
+    """csrc/minsum_wave.hip (option regular_kernel = 2): a team of lanes of one wave per shot, no workgroup barrier.  Bit-identical to the
+    reference fixtures in decode mode (clean inputs; everything else must still take the team kernel) and identical tallies in the fused
+    Monte-Carlo mode, fixed-work and early-exit, for every instantiated shape."""
+    from qldpc_amd.data import load_code
+    options("regular_kernel", 2)
+    for tag in ("bb72", "bb144", "bb288"):
+        g = golden(tag + "_minsum")
+        n = int(g["Hx_shape"][1])
+        graph = L.Graph(g["Hx_indptr"], g["Hx_indices"], n)
+        for cpl in (0, 4, 5, 6, 9):
+            options("wave_cpl", cpl)
+            for p in ("p005", "p030", "p080"):
+                base = f"Hx_{p}"
+                synd, prior = g[base + "_syndromes"], g[base + "_prior"]
+                for mi in (1, 5, 50):
+                    check(decode(L, graph, synd, prior, mi, 0), g, f"{base}_dyn_it{mi}")
+                check(decode(L, graph, synd, prior, 50, L.FLAG_FIXED_ITERS), g, f"{base}_dyn_it50")
+                for v, kw in VARIANT_KW.items():          # damping / tight clips: not eligible, must fall through to the team kernel unchanged
+                    check(decode(L, graph, synd, prior, 30, 0, **kw), g, f"{base}_{v}")
+        options("wave_cpl", 0)
+        c = load_code(tag)
+        for p, N in ((0.005, 20000), (0.04, 9001)):
+            ref = oracle.cc_sample_decode_tally(c["Hx_indptr"], c["Hx_indices"], n, c["Lx"], p, 77, 1000, N, max_iter=50, threads=0)
+            for fl in (0, L.FLAG_FIXED_ITERS):
+                for rst in (6, 7):
+                    options("wave_rst", rst)
+                    got = L.cc_sample_decode_tally(graph, c["Lx"], p, 77, 1000, N, max_iter=50, flags=fl)
+                    assert np.array_equal(got, ref), (tag, p, fl, rst, got.tolist(), ref.tolist())
+            options("wave_rst", 0)
+    # a non-uniform prior below the clip (general iteration 0) and one above it (not eligible)
+    c = load_code("bb144")
+    graph = L.Graph(c["Hx_indptr"], c["Hx_indices"], c["n"])
+    rng = np.random.default_rng(11)
+    errs = (rng.random((500, c["n"])) < 0.05).astype(np.int8)
+    synd = np.array([oracle.syndrome_check(c["Hx_indptr"], c["Hx_indices"], e) for e in errs])
+    for scale in (1.0, 9.0):
+        prior = np.full(c["n"], np.log(0.95 / 0.05)) * scale
+        prior[::5] *= 0.8
+        ref = oracle.minsum_decode_batch(c["Hx_indptr"], c["Hx_indices"], c["n"], synd, prior, max_iter=20)
+        for fl in (0, L.FLAG_FIXED_ITERS):
+            for a, b in zip(decode(L, graph, synd, prior, 20, fl), ref):
+                assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_philox_known_answer(L, oracle):
     import ctypes as C
     for ctr, key in (([0, 0, 0, 0], [0, 0]), ([0xffffffff] * 4, [0xffffffff] * 2), ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])):

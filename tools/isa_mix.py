@@ -24,8 +24,33 @@ CSRC = os.path.join(ROOT, "qldpc-branched-off_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "--cuda-device-only", "-S"]
 
-# issue classes (cycles per wave64 instruction per SIMD with >= 2 waves on it; profiles/r03_issue_rate.txt)
-CLASS_CYCLES = {"valu_f64": 4, "valu_b32": 2, "valu_b32_slow": 4, "valu_trans": 8, "valu_xlane": 4}
+# ---- issue cost of an instruction: measured table first, rules for the mnemonics the microbenchmark does not cover ----
+RATE_FILE = os.path.join(ROOT, "profiles", "r03_issue_rate.txt")
+_MEASURED = None
+
+
+def measured_cycles():
+    """{mnemonic: cycles per wave64 instruction per SIMD at >= 2 waves per SIMD}, from the microbenchmark's output on the GPU box
+    (profiles/r03_issue_rate.txt, column '4 waves per SIMD', wall-clock figure), rounded to the issue granularity of 2 cycles."""
+    global _MEASURED
+    if _MEASURED is None:
+        _MEASURED = {}
+        try:
+            with open(RATE_FILE) as fh:
+                for ln in fh:
+                    mt = re.match(r"^(\w+)\s+([\d.]+) \[\s*[\d.]+\]\s+([\d.]+) \[\s*[\d.]+\]\s+([\d.]+) \[", ln)
+                    if mt and not mt.group(1).startswith(("ds_", "mix_", "cmp_cndmask", "cmpf64")):
+                        name = mt.group(1)
+                        c = float(mt.group(4))
+                        cyc = max(2, int(round(c / 2.0)) * 2)
+                        _MEASURED[{"cndmask_b32": "v_cndmask_b32", "cndmask_vcc": "v_cndmask_b32_vcc", "readlane": "v_readlane_b32", "mov_dpp": "v_mov_b32_dpp"}.get(name, "v_" + name)] = cyc
+        except OSError:
+            pass
+    return _MEASURED
+
+
+def base_op(op):
+    return re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
 
 
 def classify(op):
@@ -43,16 +68,38 @@ def classify(op):
     if op.startswith(("global_", "flat_", "buffer_", "scratch_")):
         return "vmem"
     if op.startswith("v_"):
-        if op.startswith(("v_readlane", "v_writelane", "v_readfirstlane", "v_permlane", "v_mov_b32_dpp")) or op.endswith("_dpp"):
-            return "valu_xlane"
-        if op.startswith(("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")):
-            return "valu_trans"
-        if re.search(r"_(f64|i64|u64|b64)(_e32|_e64)?$", op) or op.startswith(("v_mad_u64_u32", "v_mad_i64_i32", "v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64")):
-            return "valu_f64"
-        if op.startswith(("v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_mul_lo_i32")):
-            return "valu_b32_slow"
-        return "valu_b32"
+        return f"valu_{valu_cycles(op)}"
     return "other"
+
+
+def valu_cycles(op):
+    """cycles one wave64 VALU instruction holds a SIMD's issue port (two or more waves on the SIMD).  Measured classes on MI355X
+    (profiles/r03_issue_rate.txt): 2 = v_add/sub_u32, and/or/xor/not, v_mov_b32, v_lshrrev / v_ashrrev, v_add / v_mul_f32;
+    4 = every f64 / 64-bit instruction, every compare, v_cndmask, every three-operand (VOP3-only) integer op (v_bfi, v_bfe, v_and_or, v_or3,
+    v_add3, v_lshl_add, v_perm, v_alignbit, v_xad), v_lshlrev_b32, v_min / v_max, v_mul_lo / hi, v_mul_u32_u24, conversions, lane moves
+    (v_readlane, DPP); 8 = transcendentals; v_fma_f32 ~ 2.5."""
+    b = base_op(op)
+    tab = measured_cycles()
+    if op.endswith("_dpp"):
+        return tab.get("v_mov_b32_dpp", 4)
+    if b in tab:
+        return tab[b]
+    if b.startswith(("v_readlane", "v_writelane", "v_readfirstlane", "v_permlane")):
+        return tab.get("v_readlane_b32", 4)
+    if b.startswith(("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")):
+        return 8
+    if re.search(r"_(f64|i64|u64|b64)$", b) or b.startswith(("v_mad_u64_u32", "v_mad_i64_i32", "v_lshl_add_u64")):
+        return tab.get("v_mad_u64_u32", 4) if b.startswith("v_mad_") else 4
+    if b.startswith(("v_cmp", "v_cndmask", "v_min", "v_max", "v_med3", "v_mul_lo", "v_mul_hi", "v_mul_u32", "v_mul_i32", "v_cvt", "v_bfi", "v_bfe", "v_and_or", "v_or3", "v_xor3",
+                     "v_add3", "v_lshl_add", "v_add_lshl", "v_lshl_or", "v_perm", "v_alignbit", "v_alignbyte", "v_xad", "v_bitop3", "v_mad_", "v_sad", "v_lshlrev_b32",
+                     "v_bcnt", "v_mbcnt", "v_ffbl", "v_ffbh", "v_bfrev", "v_fma_f64", "v_ldexp", "v_frexp", "v_fract", "v_trunc", "v_floor", "v_ceil", "v_rndne")):
+        return 4
+    if b.startswith("v_fma_f32") or b.startswith("v_fmac_f32"):
+        return 2          # 2.5 measured at 4 waves per SIMD: counted at the faster class
+    return 2
+
+
+CLASS_CYCLES = {"valu_2": 2, "valu_4": 4, "valu_8": 8, "valu_16": 16}
 
 
 def compile_to_asm(src):
@@ -196,7 +243,7 @@ def mix(ins, s, e):
 
 
 def weighted(cnt):
-    return sum(CLASS_CYCLES[c] * k for c, k in cnt.items() if c in CLASS_CYCLES)
+    return sum(int(c.split("_")[1]) * k for c, k in cnt.items() if c.startswith("valu_"))
 
 
 def describe(cnt):

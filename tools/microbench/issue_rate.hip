@@ -121,7 +121,164 @@ __global__ void k_ds_write_b64(unsigned long long *out, unsigned seed) {
     if (buf[(threadIdx.x * 7) & 1023] == 0.12345) out[0] = 0;
 }
 
+#define OP33(ins) \
+    ins " %0, %8, %0, %1\n" ins " %1, %8, %1, %2\n" ins " %2, %8, %2, %3\n" ins " %3, %8, %3, %4\n" \
+    ins " %4, %8, %4, %5\n" ins " %5, %8, %5, %6\n" ins " %6, %8, %6, %7\n" ins " %7, %8, %7, %0\n"
+#define BODY32_3(name, ins)                                                                                            \
+    __global__ void k_##name(unsigned long long *out, unsigned seed) {                                                 \
+        unsigned a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
+        unsigned b = (seed | 1) & 15;                                                                                  \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                    \
+        for (int i = 0; i < REPS; i++)                                                                                 \
+            asm volatile(R4(OP33(ins)) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b)); \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                    \
+        if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;                      \
+        if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = 0;                                           \
+    }
+// one-source ops: dst = op(src)
+#define OP31(ins) \
+    ins " %0, %1\n" ins " %1, %2\n" ins " %2, %3\n" ins " %3, %4\n" ins " %4, %5\n" ins " %5, %6\n" ins " %6, %7\n" ins " %7, %8\n"
+#define BODY1(name, ins, T)                                                                                            \
+    __global__ void k_##name(unsigned long long *out, unsigned seed) {                                                 \
+        T a0 = (T)(seed + threadIdx.x), a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
+        T b = (T)(seed | 1);                                                                                           \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                    \
+        for (int i = 0; i < REPS; i++)                                                                                 \
+            asm volatile(R4(OP31(ins)) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b)); \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                    \
+        if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;                      \
+        if (a0 == (T)0x12345 && a7 == (T)1) out[0] = 0;                                                                \
+    }
+// v_cndmask_b32 in its VOP2 form (condition in vcc)
+#define CNDV8 "v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n" \
+              "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+__global__ void k_cndmask_vcc(unsigned long long *out, unsigned seed) {
+    unsigned a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19, b = seed | 1;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(a3) : "vcc");
+    for (int i = 0; i < REPS; i++)
+        asm volatile(R4(CNDV8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = 0;
+}
+// lane-crossing moves: DPP quad permutation and ds_bpermute_b32
+__global__ void k_mov_dpp(unsigned long long *out, unsigned seed) {
+    unsigned a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < REPS; i++)
+        asm volatile(R4("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                        "v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                        "v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                        "v_mov_b32_dpp %6, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = 0;
+}
+// 64-bit multiply-add (the Philox rounds compile to it) and the compare -> select pair the decoders are full of
+__global__ void k_mad_u64_u32(unsigned long long *out, unsigned seed) {
+    unsigned long long a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    unsigned b = seed | 1, c = 0xD2511F53u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < REPS; i++)
+        asm volatile(R4("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                        "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345ull) out[0] = 0;
+}
+// pairs: v_cmp_lt_u32 vcc + v_cndmask_b32 (VOP2, vcc): cycles per PAIR
+__global__ void k_cmp_cndmask_pair(unsigned long long *out, unsigned seed) {
+    unsigned a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19, b = seed | 1;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < REPS; i++)
+        asm volatile(R4("v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_u32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                        "v_cmp_lt_u32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_u32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = 0;
+}
+// one f64 compare feeding two selects (the min-sum message select): cycles per TRIPLE
+__global__ void k_cmpf64_2cndmask(unsigned long long *out, unsigned seed) {
+    unsigned a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, b = seed | 1;
+    double d0 = 1.0 + seed, d1 = 2.0 + threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < REPS; i++)
+        asm volatile(R4("v_cmp_eq_f64 vcc, %6, %7\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n"
+                        "v_cmp_eq_f64 vcc, %7, %6\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                        "v_cmp_eq_f64 vcc, %6, %6\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "v"(d0), "v"(d1), "v"(b) : "vcc");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5) == 0x12345u) out[0] = 0;
+}
+__global__ void k_ds_bpermute(unsigned long long *out, unsigned seed) {
+    unsigned a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    const unsigned addr = ((threadIdx.x * 13 + 5) & 63) * 4;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < REPS; i++)
+        asm volatile(R4("ds_bpermute_b32 %0, %8, %1\n ds_bpermute_b32 %1, %8, %2\n ds_bpermute_b32 %2, %8, %3\n ds_bpermute_b32 %3, %8, %4\n"
+                        "ds_bpermute_b32 %4, %8, %5\n ds_bpermute_b32 %5, %8, %6\n ds_bpermute_b32 %6, %8, %7\n ds_bpermute_b32 %7, %8, %0\n s_waitcnt lgkmcnt(0)\n")
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(addr));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345u) out[0] = 0;
+}
+__global__ void k_ds_read_b32(unsigned long long *out, unsigned seed) {
+    __shared__ unsigned buf[1024 * 2];
+    buf[threadIdx.x] = seed; buf[threadIdx.x + 1024] = seed;
+    __syncthreads();
+    const unsigned addr = threadIdx.x * 4;
+    unsigned s = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < REPS; i++) {
+        unsigned x0, x1, x2, x3, x4, x5, x6, x7;
+        asm volatile(R4("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:4096\n ds_read_b32 %2, %8\n ds_read_b32 %3, %8 offset:4096\n"
+                        "ds_read_b32 %4, %8\n ds_read_b32 %5, %8 offset:4096\n ds_read_b32 %6, %8\n ds_read_b32 %7, %8 offset:4096\n")
+                     "s_waitcnt lgkmcnt(0)\n"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7) : "v"(addr) : "memory");
+        s += x0 + x7;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    if (s == 0x12345u) out[0] = 0;
+}
+__global__ void k_ds_write2_b64(unsigned long long *out, unsigned seed) {
+    __shared__ double buf[1024 * 3];
+    const unsigned addr = threadIdx.x * 16;
+    double v = seed;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < REPS; i++)
+        asm volatile(R4(R4("ds_write2_b64 %0, %1, %1 offset1:1\n ds_write2_b64 %0, %1, %1 offset0:2 offset1:3\n")) "s_waitcnt lgkmcnt(0)\n" : : "v"(addr), "v"(v) : "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    if (buf[(threadIdx.x * 7) & 1023] == 0.12345) out[0] = 0;
+}
 BODY32(xor_b32, "v_xor_b32")
+BODY32(or_b32, "v_or_b32")
+BODY32(sub_u32, "v_sub_u32")
+BODY32(lshrrev_b32, "v_lshrrev_b32")
+BODY32(ashrrev_i32, "v_ashrrev_i32")
+BODY32(min_u32, "v_min_u32")
+BODY32(mul_f32, "v_mul_f32")
+BODY32(mul_u32_u24, "v_mul_u32_u24")
+BODY32_3(and_or_b32, "v_and_or_b32")
+BODY32_3(or3_b32, "v_or3_b32")
+BODY32_3(add3_u32, "v_add3_u32")
+BODY32_3(lshl_add_u32, "v_lshl_add_u32")
+BODY32_3(bfe_u32, "v_bfe_u32")
+BODY32_3(alignbit_b32, "v_alignbit_b32")
+BODY32_3(perm_b32, "v_perm_b32")
+BODY32_3(fma_f32, "v_fma_f32")
+BODY32_3(xad_u32, "v_xad_u32")
+BODY1(mov_b32, "v_mov_b32", unsigned)
+BODY1(mov_b64, "v_mov_b64", double)
+BODY1(not_b32, "v_not_b32", unsigned)
+BODY1(cvt_f32_u32, "v_cvt_f32_u32", unsigned)
+BODY1(rcp_f32, "v_rcp_f32", float)
 BODY32(add_u32, "v_add_u32")
 BODY32(and_b32, "v_and_b32")
 BODY32(lshlrev_b32, "v_lshlrev_b32")
@@ -173,9 +330,12 @@ __global__ void k_clock(unsigned long long *out) {           // shader clock: s_
     if (a == 0x12345u) out[2] = 0;
 }
 
-struct K { const char *name; void (*fn)(unsigned long long *, unsigned); };
-#define E(n) {#n, k_##n}
-static const K kernels[] = {E(xor_b32), E(add_u32), E(and_b32), E(lshlrev_b32), E(cndmask_b32), E(bfi_b32), E(mul_lo_u32), E(mul_hi_u32), E(add_f32), E(min_f32),
+struct K { const char *name; void (*fn)(unsigned long long *, unsigned); int per_rep; };      // per_rep: instructions per loop trip
+#define E(n) {#n, k_##n, 32}
+#define EN(n, c) {#n, k_##n, c}
+static const K kernels[] = {E(xor_b32), E(or_b32), E(sub_u32), E(mov_b32), E(not_b32), E(lshrrev_b32), E(ashrrev_i32), E(min_u32), E(mul_f32), E(mul_u32_u24),
+                            E(and_or_b32), E(or3_b32), E(add3_u32), E(lshl_add_u32), E(bfe_u32), E(alignbit_b32), E(perm_b32), E(fma_f32), E(xad_u32),
+                            E(cndmask_vcc), E(cmp_cndmask_pair), EN(cmpf64_2cndmask, 36), E(mad_u64_u32), E(mov_b64), E(cvt_f32_u32), E(rcp_f32), E(mov_dpp), E(ds_bpermute), E(ds_read_b32), E(ds_write2_b64), E(add_u32), E(and_b32), E(lshlrev_b32), E(cndmask_b32), E(bfi_b32), E(mul_lo_u32), E(mul_hi_u32), E(add_f32), E(min_f32),
                             E(add_f64), E(min_f64), E(max_f64), E(mul_f64), E(cmp_lt_f64), E(cmp_eq_f64), E(cmp_lt_u32), E(cmp_eq_u64),
                             E(mix_3f64_2b32), E(readlane), E(ds_read_b64), E(ds_write_b64)};
 
@@ -217,7 +377,7 @@ int main() {
                 best_ms = std::min(best_ms, (double)ms);
                 best_span = std::min(best_span, (double)*std::max_element(h.begin(), h.begin() + nw));
             }
-            const double n_inst = (double)REPS * 32.0 * wps;
+            const double n_inst = (double)REPS * k.per_rep * wps;
             printf("  %6.2f [%6.2f]", best_ms * 1e-3 * mhz * 1e6 / n_inst, best_span / n_inst);
         }
         printf("\n");
