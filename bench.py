@@ -130,48 +130,96 @@ def pmc_entry(key):
         return None
 
 
-def valu_roofline(entry, units_per_launch, ms_per_launch, clock_mhz, floor_lane_ops_per_unit, unit_name):
-    """Binding-resource object: VALU wave-instruction issue.  `entry` carries SQ_INSTS_VALU per launch of the PMC workload and that
-    workload's units per launch; the count per unit is a property of the kernel (fixed-work legs) and carries over to this run."""
+def isa_entry(key):
+    """The committed static instruction mix of the kernel behind PMC record `key` (tools/isa_mix.py --record -> profiles/isa_mix.json), or None
+    when the kernel's sources changed since it was taken."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "isa_mix.json")) as fh:
+            e = json.load(fh)["entries"][key]
+        if e["source_digest"] != source_digest(e["sources"]):
+            return None
+        return e
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def issue_roofline(entry, mix, units_per_launch, ms_per_launch, clock_mhz, floor_cycles_per_unit, unit_name):
+    """Binding-resource object: VALU instruction ISSUE of the 1024 SIMDs, in SIMD issue-cycles.
+
+    A wave64 VALU instruction holds its SIMD's issue port for 2 cycles (add / sub / logic / shift-right / move, f32 add and mul) or 4 (every
+    f64 or 64-bit instruction, every compare and v_cndmask, every three-operand integer instruction, v_mul_lo / hi, lane moves) -- measured
+    per mnemonic on the box by tools/microbench/issue_rate.hip (profiles/r03_issue_rate.txt).  peak = 1024 SIMDs x shader clock (measured in
+    this run) issue-cycles per second.
+      achieved / frac : the ALGORITHMIC issue-cycles of the reference loop nest (every operation of kernels.py:282-359 priced
+                        at the cheapest instruction that can do it) per second, over the kernel time of THIS run (hipEvents on the launch stream)
+      issued_frac     : the issue-cycles the kernel actually spends = SQ_INSTS_VALU per unit (committed PMC pass of the same kernel) x
+                        mean cycles per VALU instruction of its steady-state loop (committed static mix, tools/isa_mix.py)
+    """
     if not entry or ms_per_launch <= 0:
         return None
-    per_unit = entry["SQ_INSTS_VALU"] / entry["units_per_launch"]
     clock = clock_mhz if clock_mhz and clock_mhz > 0 else None
-    peak = SIMDS * (clock or 2400.0) * 1e6 / 4.0
-    ach = per_unit * units_per_launch / (ms_per_launch * 1e-3)
-    out = {"bound": "valu_issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instructions/s",
-           "frac": round(ach / peak, 4),
+    peak = SIMDS * (clock or 2400.0) * 1e6                        # SIMD issue-cycles per second
+    secs = ms_per_launch * 1e-3
+    per_unit = entry["SQ_INSTS_VALU"] / entry["units_per_launch"]
+    out = {"bound": "valu_issue", "unit": "G SIMD issue-cycles/s", "peak": round(peak / 1e9, 2), "achieved": None, "frac": None,
            "clock_mhz": round(clock, 1) if clock else None,
            "clock_source": "in-kernel s_memtime / s_memrealtime, median over workgroups, this run" if clock else "ASSUMED 2400 MHz (no probe)",
-           "valu_wave_insts_per_" + unit_name: round(per_unit, 2),
            "kernel": entry["kernel"], "kernel_ms_per_launch": round(ms_per_launch, 4),
-           "pmc_source": entry.get("source", "profiles/pmc.json")}
-    if floor_lane_ops_per_unit:
-        out["algorithmic_floor_lane_ops_per_" + unit_name] = floor_lane_ops_per_unit
-        out["efficiency"] = round(floor_lane_ops_per_unit / (per_unit * 64.0), 4)     # useful lane-operations / lane-slots issued
-        out["frac_of_peak_useful"] = round(out["efficiency"] * out["frac"], 4)
-    for k in ("SQ_WAIT_ANY_frac", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "lds_bank_conflict_frac"):
+           "valu_wave_insts_per_" + unit_name: round(per_unit, 2), "pmc_source": entry.get("source", "profiles/pmc.json"),
+           "issue_rates_source": "profiles/r03_issue_rate.txt"}
+    if floor_cycles_per_unit:
+        ach = floor_cycles_per_unit * units_per_launch / secs
+        out["achieved"] = round(ach / 1e9, 2)
+        out["frac"] = round(ach / peak, 4)
+        out["algorithmic_issue_cycles_per_" + unit_name] = round(floor_cycles_per_unit, 2)
+    if mix:
+        cpi = mix["valu_issue_cycles"] / max(mix["valu_instructions"], 1)
+        issued = per_unit * cpi * units_per_launch / secs
+        tot = max(mix["valu_instructions"], 1)
+        out["issued_frac"] = round(issued / peak, 4)
+        out["issue_cycles_per_" + unit_name] = round(per_unit * cpi, 2)
+        out["issue_cycles_by_class"] = {c.replace("valu_", "") + "_cycle": round(per_unit * k / tot * int(c.split("_")[1]), 2)
+                                        for c, k in sorted(mix["mix"].items()) if c.startswith("valu_")}
+        out["mix_scope"] = mix["scope"]
+        out["code_object"] = {k: mix["code_object"].get(k) for k in ("vgpr_count", "sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size")}
+        if floor_cycles_per_unit:
+            out["efficiency"] = round(floor_cycles_per_unit / (per_unit * cpi), 4)          # algorithmic / issued issue-cycles
+    for k in ("SQ_WAIT_ANY_frac", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "lds_bank_conflict_frac", "lds_busy_frac", "valu_types"):
         if k in entry:
             out[k] = entry[k]
     tr = entry.get("hbm_bytes_per_launch")
     out["traffic"] = tr
     if tr is not None:
         scale = units_per_launch / entry["units_per_launch"]
-        gbs = tr * scale / (ms_per_launch * 1e-3) / 1e9
+        gbs = tr * scale / secs / 1e9
         out["hbm"] = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                       "note": "measured HBM bytes (PMC 2*FETCH_SIZE + WRITE_SIZE, separate passes, KB units) / kernel time: HBM is not the bound"}
     return out
 
 
-def floor_regular(m, n, cdeg, vdeg):
-    """Minimum f64 VALU lane-operations per shot-iteration of the reference loop nest (src/decoding/kernels.py:282-359) for a
-    (cdeg, vdeg)-regular graph; the count is itemised in DESIGN.md 5.1.  One operation = one lane of one vector instruction; abs / neg
-    are free operand modifiers; selecting a double costs two (two 32-bit halves)."""
-    per_edge = 3 + 2 + 4 + 2            # q = clip(v - r): sub, min, max | sign: cmp, xor | message: cmp, 2 x select, sign xor | parity: cmp, xor
-    two_smallest = {6: 14, 4: 8, 8: 20}[cdeg]       # min/max network for (min1, min2)
-    per_check = cdeg * per_edge + two_smallest + 2  # + alpha * min1, alpha * min2
-    per_var = vdeg + 1                  # R_sum over the column's checks, + prior
-    return m * per_check + n * per_var
+# issue cycles (per wave64 instruction and SIMD) of the cheapest instruction for each kind of operation (profiles/r03_issue_rate.txt)
+CYC_F64, CYC_CMP, CYC_SEL, CYC_LOGIC, CYC_BFI = 4, 4, 4, 2, 4
+
+
+def floor_regular_cycles(m, n, cdeg, vdeg):
+    """Algorithmic floor of one shot-iteration of the reference loop nest (src/decoding/kernels.py:282-359) on a (cdeg, vdeg)-regular graph, in
+    SIMD issue-cycles (lane-operations x cycles of the cheapest instruction / 64 lanes); itemised in DESIGN.md 5.1.  Per edge: q = clip(v - r)
+    sub, min, max (3 f64); sign of q folded into a running XOR of high words (1 logic); outgoing message: compare |q| with min1 (1 cmp), select
+    a double (2 selects), apply the sign (1 bit-field insert); parity of the hard decisions (1 logic).  Per check: min1 / min2 network
+    (14 f64 for degree 6) and two multiplications by alpha.  Per variable: vdeg + 1 additions."""
+    per_edge = 3 * CYC_F64 + CYC_LOGIC + CYC_CMP + 2 * CYC_SEL + CYC_BFI + CYC_LOGIC
+    two_smallest = {6: 14, 4: 8, 8: 20}[cdeg] * CYC_F64
+    per_check = cdeg * per_edge + two_smallest + 2 * CYC_F64
+    per_var = (vdeg + 1) * CYC_F64
+    return (m * per_check + n * per_var) / 64.0
+
+
+def floor_first_iteration_cycles(n):
+    """Floor of the first-iteration kernel per shot: the Philox4x32-10 stream fixed by mc_common.h -- ceil(n / 4) calls per shot, 10 rounds of two
+    32 x 32 -> 64 multiplications (v_mad_u64_u32 / v_mul_hi+lo: 4 cycles each way) and two three-input XORs (2 x 2 cycles), then four threshold
+    compares per call; the bit-sliced decode itself is < 15 % on top and not counted."""
+    calls = (n + 3) // 4
+    return calls * (10 * (2 * 4 + 4 * CYC_LOGIC) + 4 * CYC_CMP) / 64.0
 
 
 # --------------------------------------------------------------------------------------------------------------------------------
@@ -255,19 +303,20 @@ def worker(args):
             total = reduce_tally(tally)           # the one collective of the path (replaces engine.py:450-457)
             barrier()
             dt = time.perf_counter() - t0
+            ms_first = plan.first_iteration_time()
             ms_k, launches = plan.kernel_time()
             try:
                 clock = plan.clock(stream)
             except _lib.QldpcError:
                 clock = 0.0                       # unfused pipeline (irregular graph / forced streaming kernel): no probe
             plan.close()
-            return max_over_ranks(dt), total, tally, ms_k, launches, clock
+            return max_over_ranks(dt), total, tally, ms_k, launches, clock, ms_first
 
-        dt_fixed, tally_fixed, local_fixed, ms_fixed, nl_fixed, clk_fixed = run_leg(_lib.FLAG_FIXED_ITERS)
+        dt_fixed, tally_fixed, local_fixed, ms_fixed, nl_fixed, clk_fixed, _ = run_leg(_lib.FLAG_FIXED_ITERS)
         if args.legs == "fixed":
-            dt_ref, tally_ref, ms_ref, nl_ref, clk_ref = dt_fixed, tally_fixed, ms_fixed, nl_fixed, clk_fixed
+            dt_ref, tally_ref, ms_ref, nl_ref, clk_ref, ms_first = dt_fixed, tally_fixed, ms_fixed, nl_fixed, clk_fixed, 0.0
         else:
-            dt_ref, tally_ref, _, ms_ref, nl_ref, clk_ref = run_leg(0)
+            dt_ref, tally_ref, _, ms_ref, nl_ref, clk_ref, ms_first = run_leg(0)
         if not np.array_equal(tally_fixed, tally_ref):
             raise SystemExit(f"fixed-work and early-exit legs disagree: {tally_fixed.tolist()} vs {tally_ref.tolist()}")
         shots_total = world * K * B
@@ -278,7 +327,7 @@ def worker(args):
         bytes_fixed = args.max_iter * 16 * nnz + b_io
         bytes_ref = mean_iters * 16 * nnz + b_io
         regular = {(72, 36): (6, 3), (144, 72): (6, 3), (288, 144): (6, 3), (90, 45): (6, 3), (108, 54): (6, 3)}.get((n, m))
-        floor = floor_regular(m, n, *regular) if regular and args.kernel == "auto" else None
+        floor = floor_regular_cycles(m, n, *regular) if regular and args.kernel == "auto" else None
 
         def hbm_model(bytes_per_shot, ms, launches):
             if launches <= 0 or ms <= 0:
@@ -291,11 +340,17 @@ def worker(args):
 
         pm_fixed = pmc_entry(f"cc_{args.code}_fixed") if args.kernel == "auto" else None
         pm_ref = pmc_entry(f"cc_{args.code}_early_exit") if args.kernel == "auto" else None
-        roof_fixed = valu_roofline(pm_fixed, B * args.max_iter, ms_fixed / max(nl_fixed, 1), clk_fixed, floor, "shot_iteration")
+        mix_fixed = isa_entry(f"cc_{args.code}_fixed") if args.kernel == "auto" else None
+        mix_ref = isa_entry(f"cc_{args.code}_early_exit") if args.kernel == "auto" else None
+        roof_fixed = issue_roofline(pm_fixed, mix_fixed, B * args.max_iter, ms_fixed / max(nl_fixed, 1), clk_fixed, floor, "shot_iteration")
         if roof_fixed:
             roof_fixed["hbm_model"] = hbm_model(bytes_fixed, ms_fixed, nl_fixed)
-        roof_ref = valu_roofline(pm_ref, B, ms_ref / max(nl_ref, 1), clk_ref, None, "shot")
+        # reference semantics: the dominant kernel is the bit-sliced first iteration (every shot); the full decoder only sees the few shots it lists
+        ms_ref_kernel = (ms_first if ms_first > 0 else ms_ref) / max(nl_ref, 1)
+        roof_ref = issue_roofline(pm_ref if ms_first > 0 else None, mix_ref, B, ms_ref_kernel, clk_ref, floor_first_iteration_cycles(n), "shot")
         if roof_ref:
+            roof_ref["decode_ms_per_launch"] = {"first_iteration_kernel": round(ms_first / max(nl_ref, 1), 4),
+                                                "full_decoder_on_listed_shots": round((ms_ref - ms_first) / max(nl_ref, 1), 4)}
             roof_ref["hbm_model"] = hbm_model(bytes_ref, ms_ref, nl_ref)
         out.update({
             "metric": f"decoded shots/sec, {label} p={args.p:g} {args.max_iter} BP iters",
@@ -464,8 +519,10 @@ def circuit_leg(args, _lib, rank, world, local_rank, stream, barrier, reduce_tal
     osd_ms = (phases["osd_z"] + phases["osd_x"]) / max(2 * nb, 1)
     osd_shots = float(solo_tally[T["osd_z"]] + solo_tally[T["osd_x"]])
     res["roofline"] = {
-        "bp": valu_roofline(pm_bp, it_sum / max(2 * nb, 1), bp_ms, clk_bp, pm_bp.get("floor_lane_ops_per_unit") if pm_bp else None, "decode_iteration"),
-        "osd": valu_roofline(pm_osd, osd_shots / max(2 * nb, 1), osd_ms, clk_osd, pm_osd.get("floor_lane_ops_per_unit") if pm_osd else None, "osd_shot"),
+        "bp": issue_roofline(pm_bp, isa_entry(f"{args.circuit}_bp"), it_sum / max(2 * nb, 1), bp_ms, clk_bp,
+                             pm_bp.get("floor_issue_cycles_per_unit") if pm_bp else None, "decode_iteration"),
+        "osd": issue_roofline(pm_osd, isa_entry(f"{args.circuit}_osd"), osd_shots / max(2 * nb, 1), osd_ms, clk_osd,
+                              pm_osd.get("floor_issue_cycles_per_unit") if pm_osd else None, "osd_shot"),
         "note": "per launch of one sector, from the exclusive (one-stream) batch",
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

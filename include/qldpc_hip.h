@@ -54,28 +54,24 @@ extern "C" {
 #define QLDPC_FLAG_KERNEL_RESIDENT 0x20 /* force the LDS/register-resident kernels (small graphs only) */
 #define QLDPC_FLAG_KERNEL_GENERIC 0x40  /* resident family: use the generic (irregular-degree) kernel even for regular graphs */
 #define QLDPC_FLAG_MC_UNFUSED 0x80      /* Monte-Carlo plans: separate sample / decode / judge launches instead of the fused kernel */
-/* kernel-variant selectors (parity tests and measurements; results are identical whichever is chosen) */
-#define QLDPC_FLAG_WG_EDGE_LANES 0x2     /* workgroup-per-shot decoder: check pass with 16 lanes per check and shuffle reductions (SURVEY 7-6
-                                           option B; measured slower than thread-per-check, profiles/r02_bp_lane_mapping.txt) */
-#define QLDPC_FLAG_OSD_PIPED 0x4         /* OSD-0: pivot resolution of block i+1 overlapped with the row updates of block i (512 <= m <= 1024;
-                                           measured slower than the default, profiles/r02_osd_experiments.txt) */
-#define QLDPC_FLAG_OSD_P2WAVES 0x8       /* OSD-0 LDS kernel: pivots of a block resolved by four waves with a barrier per pivot (the round-1 form)
-                                           instead of one wave on registers */
-#define QLDPC_FLAG_OSD_P3SERIAL 0x10000  /* OSD-0 LDS kernel: row updates test one operation after the other (the round-1 form) instead of reading
-                                           a block's tested bits at once */
+/* size-class selectors of the product library (parity tests force every class on small inputs; results are identical whichever runs) */
 #define QLDPC_FLAG_OSD_LDS 0x20000      /* OSD-0: the row-transform kernel even for small matrices (m <= 128, n <= 1024), which otherwise take the
                                            literal one-wave-per-shot elimination */
-#define QLDPC_FLAG_WG_IDXLOAD 0x40000   /* workgroup-per-shot decoder: reload the row's column indices every iteration even where a thread owns one
-                                           row for the whole launch (m <= 1024) and keeps them in registers by default */
 #define QLDPC_FLAG_WG_VGLOBAL 0x100     /* workgroup-per-shot decoder: posteriors in HBM/L2 even when they fit LDS (the large-graph form) */
 #define QLDPC_FLAG_WG_GENERIC 0x200     /* workgroup-per-shot decoder: the any-input kernel even for host-verified clean inputs */
 #define QLDPC_FLAG_OSD_UG 0x400         /* OSD-0: row transform in HBM/L2 even when it fits LDS (the m > 1024 form) */
 #define QLDPC_FLAG_OSD_GLOBAL 0x800     /* OSD-0: the literal global-memory elimination (general fallback) */
-#define QLDPC_FLAG_OSD_NOKILL 0x1000    /* OSD-0: no parallel dependent-column tests */
-#define QLDPC_FLAG_OSD_FWD 0x2000       /* OSD-0: the forward-elimination + back-substitution kernel (m <= 1024; measured slower than the default
-                                           Gauss-Jordan LDS kernel on the circuit-level matrices, kept as a checked alternative) */
-#define QLDPC_FLAG_CLOCK_PROBE 0x4000   /* plans: workgroups stamp s_memtime / s_memrealtime around their work (see *_plan_clock) */
 #define QLDPC_FLAG_WG_ROWMAJOR 0x8000   /* workgroup-per-shot decoder: natural row / column order instead of the degree-sorted assignment */
+#define QLDPC_FLAG_CLOCK_PROBE 0x4000   /* plans: workgroups stamp s_memtime / s_memrealtime around their work (see *_plan_clock) */
+/* measured-and-rejected kernels: libqldpc_hip_experiments.so only (make -C csrc experiments; same ABI, loaded by the parity tests).  The product
+ * library answers these with QLDPC_ERR_UNSUPPORTED.  Numbers: profiles/r02_osd_experiments.txt, r02_bp_lane_mapping.txt, r03_wave_kernel.txt */
+#define QLDPC_FLAG_WG_EDGE_LANES 0x2     /* workgroup-per-shot decoder: check pass with 16 lanes per check and shuffle reductions (SURVEY 7-6 option B) */
+#define QLDPC_FLAG_OSD_PIPED 0x4         /* OSD-0: pivot resolution of block i+1 overlapped with the row updates of block i (512 <= m <= 1024) */
+#define QLDPC_FLAG_OSD_P2WAVES 0x8       /* OSD-0 LDS kernel: pivots of a block resolved by four waves with a barrier per pivot (the round-1 form) */
+#define QLDPC_FLAG_OSD_P3SERIAL 0x10000  /* OSD-0 LDS kernel: row updates test one operation after the other (the round-1 form) */
+#define QLDPC_FLAG_WG_IDXLOAD 0x40000    /* workgroup-per-shot decoder: reload the row's column indices every iteration (m <= 1024 keeps them in registers) */
+#define QLDPC_FLAG_OSD_NOKILL 0x1000     /* OSD-0: no parallel dependent-column tests */
+#define QLDPC_FLAG_OSD_FWD 0x2000        /* OSD-0: the forward-elimination + back-substitution kernel (m <= 1024) */
 
 /* tally slots written by the *_sample_decode_tally entry points (int64[QLDPC_TALLY_SLOTS]);
  * replaces the Python tally loop of src/simulation/engine.py:450-457 */
@@ -101,12 +97,14 @@ const char *qldpc_last_error(void);
 int qldpc_version(void);
 /* number of usable HIP devices (0 when none; never fails) */
 int qldpc_device_count(void);
-/* Process-wide kernel-selection switches for tools/ and the parity tests.  Results never depend on them (every selectable kernel is
- * checked against the same fixtures); the defaults are what bench.py measures.  New here (the reference has no counterpart).
- *   "regular_kernel"  code-capacity decoder for (6,3)-regular graphs: 0 = automatic, 1 = 72-thread teams with workgroup barriers
- *                     (csrc/minsum_regular.hip), 2 = wave-private teams, no barrier (csrc/minsum_wave.hip) where the inputs allow it
- *   "wave_cpl" / "wave_rst" / "wave_grid"  shape of the wave-private kernel: checks per lane (0 = automatic, 4, 5, 6, 9), row stride of
- *                     its message buffer in doubles (0, 6, 7), waves per CU of its persistent grid (0 .. 32) */
+/* Process-wide kernel-selection switches for tools/ and the parity tests.  Results never depend on them (every selectable path is checked
+ * against the same fixtures); the defaults are what bench.py measures.  New here (the reference has no counterpart).
+ *   "mc_first_iteration"  reference-semantics Monte-Carlo plans: 1 (default) = bit-sliced first iteration (csrc/mc_first.hip) + the full decoder
+ *                         on the shots it lists, 0 = the full decoder for every shot
+ *   "mc_first_bits"       shots per lane of that kernel: 8 (default), 16, 32
+ *   "mc_tail_overlap"     1 (default; read at plan creation) = OSD-0 + judge of a batch on a side stream beside the next batch's decode
+ *   "regular_kernel", "wave_cpl", "wave_rst", "wave_grid"  experiments build only: the wave-private decoder (csrc/minsum_wave.hip); the
+ *                         product library accepts 0 and answers anything else with QLDPC_ERR_UNSUPPORTED */
 int qldpc_set_option(const char *name, int value);
 
 /* Build a Tanner-graph handle on `device`.  Validates the CSR (monotone indptr, 0 <= col < n, strictly
@@ -214,6 +212,9 @@ int qldpc_cc_plan_read(qldpc_cc_plan *plan, void *stream, int clear, int64_t *ta
 /* time of the decode kernel launches enqueued since the last call, measured with hipEvents on the launch
  * stream (ms, summed) and their count; used by bench.py for the roofline line. */
 int qldpc_cc_plan_kernel_time(qldpc_cc_plan *plan, double *ms_total, int64_t *launches);
+/* the part of that total spent in the bit-sliced first-iteration kernel of the reference-semantics pipeline (csrc/mc_first.hip; 0 for plans
+ * that do not use it).  Call before qldpc_cc_plan_kernel_time, which resets both sums. */
+int qldpc_cc_plan_first_iteration_time(qldpc_cc_plan *plan, double *ms_first);
 /* shader clock (MHz) held under the last decode launch (plans created with QLDPC_FLAG_CLOCK_PROBE; fused regular kernel only):
  * median over workgroups of delta(s_memtime) / delta(s_memrealtime) x 100 MHz.  Synchronises `stream`. */
 int qldpc_cc_plan_clock(qldpc_cc_plan *plan, void *stream, double *mhz);

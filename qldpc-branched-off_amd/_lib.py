@@ -8,8 +8,20 @@ from collections import OrderedDict
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# QLDPC_HIP_SO selects another build of the same ABI at import time (tools/: the diagnostic build with OSD phase timers)
-SO_PATH = os.environ.get("QLDPC_HIP_SO") or os.path.join(_HERE, "csrc", "libqldpc_hip.so")
+# the product library.  select_build() switches THIS module to another build of the same ABI before the library is first used:
+#   "experiments"  libqldpc_hip_experiments.so: plus the measured-and-rejected kernels (the parity tests load it through tests/conftest.py)
+#   "timers"       libqldpc_hip_timers.so: clock reads inside the kernels (tools/ diagnostics; make -C csrc timers)
+SO_PATH = os.path.join(_HERE, "csrc", "libqldpc_hip.so")
+BUILD = "product"
+
+
+def select_build(name):
+    """Point this module at another build of the library ("product", "experiments", "timers").  Only before the first call into it."""
+    global SO_PATH, BUILD
+    if _lib is not None and name != BUILD:
+        raise QldpcError(f"library already loaded ({BUILD}); select_build must come first")
+    fn = {"product": "libqldpc_hip.so", "experiments": "libqldpc_hip_experiments.so", "timers": "libqldpc_hip_timers.so"}[name]
+    SO_PATH, BUILD = os.path.join(_HERE, "csrc", fn), name
 
 ALPHA_CONST, ALPHA_DYNAMIC, ALPHA_SEQ = 0, 1, 2
 FLAG_FIXED_ITERS, FLAG_KERNEL_STREAM, FLAG_KERNEL_RESIDENT, FLAG_KERNEL_GENERIC, FLAG_MC_UNFUSED = 0x1, 0x10, 0x20, 0x40, 0x80
@@ -397,6 +409,12 @@ class CodeCapacityPlan:
         tally = np.zeros(TALLY_SLOTS, np.int64)
         check(lib().qldpc_cc_plan_read(self._h, C.c_void_p(stream), C.c_int(int(clear)), ptr(tally, C.c_int64)))
         return tally
+
+    def first_iteration_time(self):
+        """ms spent in the bit-sliced first-iteration kernel since the last kernel_time() (call before it)"""
+        ms = C.c_double()
+        check(lib().qldpc_cc_plan_first_iteration_time(self._h, C.byref(ms)))
+        return ms.value
 
     def kernel_time(self):
         ms, nl = C.c_double(0), C.c_int64(0)

@@ -230,6 +230,26 @@ static int phase_mark(qldpc_circuit_plan *P, int phase, hipStream_t s, bool open
     return QLDPC_OK;
 }
 
+// Folds finished phase brackets into phase_ms and hands their events back to the pool; every entry leaves `pending` before its events enter the
+// pool (an entry is never in both).  wait = false: only brackets whose closing event has already completed (no host wait).
+static void drain_phases(qldpc_circuit_plan *P, bool wait) {
+    size_t keep = 0;
+    for (size_t i = 0; i < P->pending.size(); i++) {
+        const qldpc_circuit_plan::Bracket br = P->pending[i];
+        if (!br.b) {                                       // an opener whose launches failed before the closing mark
+            if (wait) P->pool.push_back(br.a); else P->pending[keep++] = br;
+            continue;
+        }
+        const bool done = wait ? (hipEventSynchronize(br.b) == hipSuccess) : (hipEventQuery(br.b) == hipSuccess);
+        if (!done && !wait) { P->pending[keep++] = br; continue; }
+        float t = 0;
+        if (done && hipEventElapsedTime(&t, br.a, br.b) == hipSuccess) P->phase_ms[br.phase] += t;
+        P->pool.push_back(br.a); P->pool.push_back(br.b);
+    }
+    P->pending.resize(keep);
+    (void)hipGetLastError();                               // hipEventQuery's hipErrorNotReady is not an error of the caller
+}
+
 template <class T>
 static int up(DevBuf &b, const std::vector<T> &v) {
     int rc = b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T));
@@ -476,6 +496,7 @@ static int circuit_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin
     if (outcome && (rc = P->d_outcome.ensure((size_t)P->batch)) != QLDPC_OK) return rc;
     for (int64_t off = 0; off < count; off += P->batch) {
         const int64_t B = std::min<int64_t>(P->batch, count - off);
+        if (P->pending.size() > 256) drain_phases(P, false);         // a caller that never reads phase times: recycle finished brackets (bounded event count)
         if ((rc = phase_mark(P, QLDPC_PHASE_SAMPLE, s, true)) != QLDPC_OK) return rc;
         if ((rc = launch_sampler(P, seed, trial_begin + off, B, s)) != QLDPC_OK) return rc;
         if ((rc = phase_mark(P, QLDPC_PHASE_SAMPLE, s, false)) != QLDPC_OK) return rc;
@@ -528,6 +549,8 @@ QLDPC_EXPORT int qldpc_circuit_plan_read(qldpc_circuit_plan *P, void *stream, in
     QLDPC_USE_DEVICE(P->device);
     int rc = QLDPC_OK; (void)rc;
     QLDPC_HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    if (P->side) QLDPC_HIP_TRY(hipStreamSynchronize(P->side));
+    drain_phases(P, true);                                           // everything enqueued has finished: fold the brackets, recycle their events
     QLDPC_HIP_TRY(hipMemcpy(tally, P->d_tally.p, QLDPC_TALLY_SLOTS * 8, hipMemcpyDeviceToHost));
     if (clear) QLDPC_HIP_TRY(hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8));
     return QLDPC_OK;
@@ -565,17 +588,7 @@ QLDPC_EXPORT int qldpc_circuit_plan_sample(qldpc_circuit_plan *P, uint64_t seed,
 QLDPC_EXPORT int qldpc_circuit_plan_phase_times(qldpc_circuit_plan *P, double *ms, int64_t *batches) {
     QLDPC_REQUIRE(P != nullptr && ms != nullptr, "NULL argument");
     QLDPC_USE_DEVICE(P->device);
-    for (auto &br : P->pending) {
-        if (br.b) {
-            QLDPC_HIP_TRY(hipEventSynchronize(br.b));
-            float t = 0;
-            QLDPC_HIP_TRY(hipEventElapsedTime(&t, br.a, br.b));
-            P->phase_ms[br.phase] += t;
-            P->pool.push_back(br.b);
-        }
-        P->pool.push_back(br.a);
-    }
-    P->pending.clear();
+    drain_phases(P, true);
     for (int i = 0; i < QLDPC_CIRCUIT_PHASES; i++) { ms[i] = P->phase_ms[i]; P->phase_ms[i] = 0; }
     if (batches) *batches = P->batches;
     P->batches = 0;

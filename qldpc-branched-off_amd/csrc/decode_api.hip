@@ -39,9 +39,11 @@ static int dispatch_kernel(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     const bool want_res = flags & (QLDPC_FLAG_KERNEL_RESIDENT | QLDPC_FLAG_KERNEL_GENERIC);
     const bool can_res = resident_supported(g, damping);
     if (!want_stream && !(flags & QLDPC_FLAG_KERNEL_GENERIC) && regular_supported(g, clip, max_iter)) {
+#ifdef QLDPC_EXPERIMENTS
         const bool clean = nanfree && (flags & QLDPC_FLAG_INTERNAL_PRIOR_LE_CLIP);
         if (wave_kernel_choice() == 2 && wave_supported(g, damping, clean))
             return minsum_wave_launch(g, B, d_synd, d_prior, max_iter, d_alpha, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
+#endif
         return minsum_regular_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
     }
     if (want_res && !can_res) {
@@ -63,8 +65,8 @@ int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     int rc = g->ws_acquire(stream);
     if (rc != QLDPC_OK) return rc;
     rc = dispatch_kernel(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
-    if (rc != QLDPC_OK) return rc;
-    return g->ws_release(stream);
+    const int rel = g->ws_release(stream);          // always: a failing call may have enqueued launches the next stream has to wait for
+    return rc != QLDPC_OK ? rc : rel;
 }
 
 }  // namespace qldpc

@@ -203,13 +203,13 @@ static int osd0_global_launch(const qldpc_graph *g, const int32_t *d_list, const
 int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
                        const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream) {
     if (g->m == 0 || g->n == 0) return QLDPC_OK;
-    int rc = g->ws_acquire(stream);
+    int rc = g->ws_acquire(stream);                 // (a no-op for a caller that already holds the workspaces on this stream)
     if (rc != QLDPC_OK) return rc;
     bool handled = false;           // LDS-resident kernels for m <= 4096; the global-memory kernel is the general fallback
     rc = osd0_lds_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
     if (rc == QLDPC_OK && !handled) rc = osd0_global_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, stream);
-    if (rc != QLDPC_OK) return rc;
-    return g->ws_release(stream);
+    const int rel = g->ws_release(stream);          // always: a failing call may have enqueued launches the next stream has to wait for
+    return rc != QLDPC_OK ? rc : rel;
 }
 
 static int osd0_global_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
@@ -566,7 +566,10 @@ QLDPC_EXPORT int qldpc_osd0_batch_dev(const qldpc_graph *g, int64_t B, const int
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> lk(g->mu);
     if (!d_select) {
-        if ((rc = g->ws_list.ensure((size_t)B * 4 + 16)) != QLDPC_OK) return rc;
+        // the iota list lives in a shared workspace: order this stream behind its previous user BEFORE touching it (an OSD kernel still in flight on
+        // another stream reads count and list from the same buffer)
+        if ((rc = g->ws_acquire(s)) != QLDPC_OK) return rc;
+        if ((rc = g->ws_list.ensure((size_t)B * 4 + 16)) != QLDPC_OK) { (void)g->ws_release(s); return rc; }
         int32_t *cnt = g->ws_list.as<int32_t>(), *list = cnt + 4;
         hipLaunchKernelGGL(iota_list_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, list, cnt);
         d_select = list; d_select_count = cnt;
@@ -688,6 +691,11 @@ template <bool UG>
 __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     extern __shared__ unsigned char lds[];
     const int m = P.m, n = P.n, mw = P.mw, K = P.K, cd = P.cdeg, tid = threadIdx.x, T = blockDim.x;
+#ifdef QLDPC_EXPERIMENTS       // measured-and-rejected forms of the phases (profiles/r02_osd_experiments.txt) exist in the experiments build only
+    const bool x_nokill = P.nokill, x_p2waves = P.p2waves, x_p3serial = P.p3serial;
+#else
+    constexpr bool x_nokill = false, x_p2waves = false, x_p3serial = false;
+#endif
     unsigned long long *U;
     if (UG) U = P.ug + (size_t)blockIdx.x * (size_t)(m + 2) * mw; else U = reinterpret_cast<unsigned long long *>(lds);
     uint16_t *sidx = reinterpret_cast<uint16_t *>(lds + P.offIdx);         // [K] columns of the current chunk
@@ -785,7 +793,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 }
             };
             bool kill_due = false;                                           // a block met dependent columns: test the rest of the chunk (deferred, see phase 2)
-            if (row > 0 && !P.nokill) {                                      // a fresh chunk late in the sweep is mostly dependent columns: one pass up
+            if (row > 0 && !x_nokill) {                                      // a fresh chunk late in the sweep is mostly dependent columns: one pass up
                 long long tk = OSD_CLOCK();                                    // front instead of one serial pivot step per dependent column
                 d_kills++;
                 kill_pass(0, tid, T);
@@ -842,7 +850,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 // (1.7 M cycles per shot), one wave per column (1.85 M), four columns resolved inside a wave per barrier (1.75 M);
                 // this form: 1.36 M -- the cost is the dependent ballot -> scalar -> lane-read chain of a step, not the barrier.
                 int nops = 0, anydep = 0;
-                if (!UG && !P.p2waves) {
+                if (!UG && !x_p2waves) {
                     // rows of <= 16 words: the whole block in wave 0, registers only (quad_pivot_step above); the other waves wait at the barrier
                     if (tid < 64) {
                         const int lane = tid, g = lane & 3, w = lane >> 2, wq = row >> 6;
@@ -960,7 +968,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                         }
                     }
                 };
-                if (!P.p3serial && nops > 0) {
+                if (!x_p3serial && nops > 0) {
                     // rows in LDS: osd_rows_apply (osd_common.h) -- tested bits of the whole block read at once, only touched operations visited;
                     // rows in HBM/L2 (UG): the same scheme written out below on the word-major transform
                     int ppv = opp[tid & 15], ptv = opt[tid & 15];           // operation k's (pp, column) sit in lane k of every 16
@@ -1058,8 +1066,8 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 c_p3 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
                 if (row >= P.rankH || row >= m) { finished = true; break; }
                 // ---- dependent columns were met: drop every column of the chunk that is dependent by now ----
-                if (anydep && !P.nokill) {
-                    if (!UG && !P.p2waves) {
+                if (anydep && !x_nokill) {
+                    if (!UG && !x_p2waves) {
                         kill_due = true;                                     // done by the idle waves beside the next block's pivot chain (phase 2 above)
                     } else {
                         d_kills++;
@@ -1169,6 +1177,12 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
         const int rcs = osd0_small_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, stream, handled);
         if (rcs != QLDPC_OK || handled) return rcs;
     }
+#ifndef QLDPC_EXPERIMENTS
+    if (flags & (QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_P2WAVES | QLDPC_FLAG_OSD_P3SERIAL | QLDPC_FLAG_OSD_NOKILL)) {
+        set_error("this OSD-0 variant (flags %#x) is a measured-and-rejected experiment: it exists in libqldpc_hip_experiments.so only (make experiments)", flags);
+        return QLDPC_ERR_UNSUPPORTED;
+    }
+#else
     if ((flags & QLDPC_FLAG_OSD_FWD) && !(flags & (QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // the forward-elimination kernel (m <= 1024)
         const int rcf = osd0_fwd_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
         if (rcf != QLDPC_OK || handled) return rcf;
@@ -1177,6 +1191,7 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
         const int rcp = osd0_pipe_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
         if (rcp != QLDPC_OK || handled) return rcp;
     }
+#endif
     const int mode = (flags & QLDPC_FLAG_OSD_GLOBAL) ? 0 : plan_osd_lds(g, P, lds, flags);
     if (mode == 0) return QLDPC_OK;
     if (g->gf2_rank < 0) g->gf2_rank = host_gf2_rank(g);      // callers hold g->mu

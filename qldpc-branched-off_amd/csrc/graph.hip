@@ -41,11 +41,12 @@ int DeviceScope::enter(int device) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
     const int rc = use_device(device);
-    if (rc == QLDPC_OK && cur >= 0 && cur != device) prev = cur;
+    if (rc == QLDPC_OK && cur >= 0) prev = cur;        // recorded unconditionally: an entry point may walk through several devices (comm.hip)
     return rc;
 }
 DeviceScope::~DeviceScope() {
-    if (prev >= 0) (void)hipSetDevice(prev);
+    int cur = -1;
+    if (prev >= 0 && (hipGetDevice(&cur) != hipSuccess || cur != prev)) (void)hipSetDevice(prev);
 }
 
 int ensure_max_lds(int device, const void *func, int bytes) {

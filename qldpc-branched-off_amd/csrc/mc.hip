@@ -123,12 +123,21 @@ struct qldpc_cc_plan {
     std::vector<double> alpha;
     DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol, d_cold, d_clk;
     DevBuf d_lptr, d_lidx, d_cont;        // logical rows in CSR form and the list of shots the bit-sliced first iteration hands on (mc_first.hip)
+    // Fused pipeline: the tail of a batch (OSD-0 on its BP failures + their judge: a latency-bound ~0.1 ms on a handful of CUs) runs on the plan's
+    // side stream beside the NEXT batch's decode.  Failure records are double-buffered: set i = batch parity; set 0 is the buffers above.
+    DevBuf d_err2, d_synd2, d_dec2, d_llr2, d_list2, d_count2, d_cold2;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_decoded[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+    bool tail_pending[2] = {false, false};
+    int64_t batch_no = 0;
     bool clk_first = false;               // the last launch stamped the first-iteration kernel's probe buffer
     bool first_ok = false;                // the closed form of iteration 0 applies to this plan (uniform prior > 0, column degree <= 3, ...)
     unsigned negbits = 0;
     bool fused = false, nanfree = false, clean = false;      // clean: nanfree and |prior| <= clip (what the wave-private kernel needs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decode-kernel brackets not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_first;   // ... and those of the first-iteration kernel alone (a part of the bracket above)
+    double ms_first = 0;
     std::vector<hipEvent_t> pool;
     double ms_total = 0;
     int64_t launches = 0;
@@ -214,6 +223,19 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
                                        P->d_synd.as<int8_t>(), P->d_err.as<int8_t>(), P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
                                        (flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() : nullptr)) != QLDPC_OK)
             return fail(rc);
+        if (mc_tail_overlap_choice() == 1 && use_osd) {
+            if ((rc = P->d_err2.ensure(batch * n)) || (rc = P->d_synd2.ensure(batch * m)) || (rc = P->d_dec2.ensure(batch * n)) || (rc = P->d_llr2.ensure(batch * n * 8)) ||
+                (rc = P->d_list2.ensure(batch * 4)) || (rc = P->d_count2.ensure(16)) || (rc = P->d_cold2.ensure(mc_regular_cold_bytes())))
+                return fail(rc);
+            if ((rc = mc_regular_fill_cold(P->d_cold2.p, P->d_tally.as<unsigned long long>(), P->d_count2.as<int32_t>(), P->d_list2.as<int32_t>(),
+                                           P->d_synd2.as<int8_t>(), P->d_err2.as<int8_t>(), P->d_dec2.as<int8_t>(), P->d_llr2.as<double>(),
+                                           (flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() : nullptr)) != QLDPC_OK)
+                return fail(rc);
+            bool ok = hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 2 && ok; i++)
+                ok = hipEventCreateWithFlags(&P->ev_decoded[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&P->ev_tail[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) { set_error("stream / event creation failed: %s", hipGetErrorString(hipGetLastError())); return fail(QLDPC_ERR_HIP); }
+        }
     }
     *out = P;
     return QLDPC_OK;
@@ -232,7 +254,13 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
         if (P->fused) {
             // one launch: sample -> syndrome -> decode -> logical compare -> tally; BP failures are exported for OSD-0.
             // The failure records reuse the per-shot buffers of the unfused path (synd/err/dec/llr), compacted.
-            QLDPC_HIP_TRY(hipMemsetAsync(P->d_count.p, 0, 16, s));          // [0] BP failures (OSD-0 list), [2] shots handed on by the first iteration
+            // failure-record set of this batch; its previous user (the tail of batch k - 2 on the side stream) must be done
+            const int set = P->side ? (int)(P->batch_no & 1) : 0;
+            P->batch_no++;
+            DevBuf &b_count = set ? P->d_count2 : P->d_count, &b_list = set ? P->d_list2 : P->d_list, &b_synd = set ? P->d_synd2 : P->d_synd,
+                   &b_err = set ? P->d_err2 : P->d_err, &b_dec = set ? P->d_dec2 : P->d_dec, &b_llr = set ? P->d_llr2 : P->d_llr, &b_cold = set ? P->d_cold2 : P->d_cold;
+            if (P->side && P->tail_pending[set]) QLDPC_HIP_TRY(hipStreamWaitEvent(s, P->ev_tail[set], 0));
+            QLDPC_HIP_TRY(hipMemsetAsync(b_count.p, 0, 16, s));          // [0] BP failures (OSD-0 list), [2] shots handed on by the first iteration
             hipEvent_t e0 = get_event(P), e1 = get_event(P);
             if (e0 && e1) QLDPC_HIP_TRY(hipEventRecord(e0, s));
             if (P->first_ok && mc_first_choice() == 1 && wave_kernel_choice() != 2) {
@@ -240,27 +268,38 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
                 unsigned long long *clk = (P->flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() + 2 * kClkSlots : nullptr;
                 P->clk_first = true;
                 if ((rc = mc_first_launch(g, P->k, P->d_lptr.as<int32_t>(), P->d_lidx.as<int32_t>(), B, seed, shot_begin + off, P->thr, P->negbits,
-                                          P->d_tally.as<unsigned long long>(), P->d_cont.as<int32_t>(), P->d_count.as<int32_t>() + 2, clk, s)) != QLDPC_OK)
+                                          P->d_tally.as<unsigned long long>(), P->d_cont.as<int32_t>(), b_count.as<int32_t>() + 2, clk, s)) != QLDPC_OK)
                     return rc;
+                if (e0) { hipEvent_t em = get_event(P); if (em) { QLDPC_HIP_TRY(hipEventRecord(em, s)); P->pending_first.emplace_back(e0, em); } }
                 rc = mc_regular_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags & ~QLDPC_FLAG_CLOCK_PROBE, P->nanfree, seed,
-                                       shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_cold.p, s, P->d_cont.as<int32_t>(),
-                                       P->d_count.as<int32_t>() + 2);
-            } else if ((P->clk_first = false), wave_kernel_choice() == 2 && wave_supported(g, P->damping, P->clean))
+                                       shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), b_cold.p, s, P->d_cont.as<int32_t>(),
+                                       b_count.as<int32_t>() + 2);
+            }
+#ifdef QLDPC_EXPERIMENTS
+            else if ((P->clk_first = false), wave_kernel_choice() == 2 && wave_supported(g, P->damping, P->clean))
                 rc = mc_wave_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, seed, shot_begin + off,
-                                    P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_cold.p, s);
-            else
+                                    P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), b_cold.p, s);
+#endif
+            else if ((P->clk_first = false), true)
                 rc = mc_regular_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, P->nanfree, seed,
-                                       shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), P->d_cold.p, s);
+                                       shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), b_cold.p, s);
             if (rc != QLDPC_OK) return rc;
             if (e0 && e1) { QLDPC_HIP_TRY(hipEventRecord(e1, s)); P->pending.emplace_back(e0, e1); }
             if (P->use_osd) {
+                hipStream_t ts = s;
+                if (P->side) {                                           // the tail follows the decode on the side stream
+                    ts = P->side;
+                    QLDPC_HIP_TRY(hipEventRecord(P->ev_decoded[set], s));
+                    QLDPC_HIP_TRY(hipStreamWaitEvent(ts, P->ev_decoded[set], 0));
+                }
                 std::lock_guard<std::mutex> lk(g->mu);
-                if ((rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), P->d_synd.as<int8_t>(), P->d_llr.as<double>(),
-                                             P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), P->flags, s)) != QLDPC_OK)
+                if ((rc = osd0_listed_launch(g, b_list.as<int32_t>(), b_count.as<int32_t>(), b_synd.as<int8_t>(), b_llr.as<double>(),
+                                             b_dec.as<int8_t>(), nullptr, b_dec.as<int8_t>(), P->flags, ts)) != QLDPC_OK)
                     return rc;
-                if ((rc = judge_failed_launch(g, P->d_count.as<int32_t>(), P->d_Lmask.as<uint64_t>(), P->d_err.as<int8_t>(), P->d_synd.as<int8_t>(),
-                                              P->d_dec.as<int8_t>(), P->d_tally.as<unsigned long long>(), s)) != QLDPC_OK)
+                if ((rc = judge_failed_launch(g, b_count.as<int32_t>(), P->d_Lmask.as<uint64_t>(), b_err.as<int8_t>(), b_synd.as<int8_t>(),
+                                              b_dec.as<int8_t>(), P->d_tally.as<unsigned long long>(), ts)) != QLDPC_OK)
                     return rc;
+                if (P->side) { QLDPC_HIP_TRY(hipEventRecord(P->ev_tail[set], ts)); P->tail_pending[set] = true; }
             }
             continue;
         }
@@ -303,6 +342,14 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
 }
 
 static int drain_events(qldpc_cc_plan *P) {
+    for (auto &pr : P->pending_first) {          // (first, mid): `first` is shared with the whole-decode bracket and returns to the pool there
+        QLDPC_HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0;
+        QLDPC_HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        P->ms_first += ms;
+        P->pool.push_back(pr.second);
+    }
+    P->pending_first.clear();
     for (auto &pr : P->pending) {
         QLDPC_HIP_TRY(hipEventSynchronize(pr.second));
         float ms = 0;
@@ -320,6 +367,7 @@ QLDPC_EXPORT int qldpc_cc_plan_read(qldpc_cc_plan *P, void *stream, int clear, i
     int rc = QLDPC_OK; (void)rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     QLDPC_HIP_TRY(hipStreamSynchronize(s));
+    if (P->side) { QLDPC_HIP_TRY(hipStreamSynchronize(P->side)); P->tail_pending[0] = P->tail_pending[1] = false; }
     QLDPC_HIP_TRY(hipMemcpy(tally, P->d_tally.p, QLDPC_TALLY_SLOTS * 8, hipMemcpyDeviceToHost));
     if (clear) QLDPC_HIP_TRY(hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8));
     return QLDPC_OK;
@@ -331,7 +379,17 @@ QLDPC_EXPORT int qldpc_cc_plan_kernel_time(qldpc_cc_plan *P, double *ms_total, i
     if (rc != QLDPC_OK) return rc;
     if (ms_total) *ms_total = P->ms_total;
     if (launches) *launches = P->launches;
-    P->ms_total = 0; P->launches = 0;
+    P->ms_total = 0; P->launches = 0; P->ms_first = 0;
+    return QLDPC_OK;
+}
+
+// the part of qldpc_cc_plan_kernel_time's total spent in the bit-sliced first-iteration kernel (0 when the plan does not use it); call BEFORE
+// qldpc_cc_plan_kernel_time, which resets both sums
+QLDPC_EXPORT int qldpc_cc_plan_first_iteration_time(qldpc_cc_plan *P, double *ms_first) {
+    QLDPC_REQUIRE(P != nullptr && ms_first != nullptr, "NULL argument");
+    int rc = drain_events(P);
+    if (rc != QLDPC_OK) return rc;
+    *ms_first = P->ms_first;
     return QLDPC_OK;
 }
 
@@ -350,9 +408,13 @@ QLDPC_EXPORT void qldpc_cc_plan_destroy(qldpc_cc_plan *P) {
     if (!P) return;
     (void)hipSetDevice(P->g->device);
     for (auto &pr : P->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pr : P->pending_first) (void)hipEventDestroy(pr.second);
     for (auto e : P->pool) (void)hipEventDestroy(e);
+    if (P->side) { (void)hipStreamSynchronize(P->side); (void)hipStreamDestroy(P->side); }
+    for (int i = 0; i < 2; i++) { if (P->ev_decoded[i]) (void)hipEventDestroy(P->ev_decoded[i]); if (P->ev_tail[i]) (void)hipEventDestroy(P->ev_tail[i]); }
     for (DevBuf *b : {&P->d_alpha, &P->d_prior, &P->d_Lmask, &P->d_err, &P->d_synd, &P->d_dec, &P->d_llr, &P->d_conv, &P->d_iter,
-                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol, &P->d_cold, &P->d_clk, &P->d_lptr, &P->d_lidx, &P->d_cont})
+                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol, &P->d_cold, &P->d_clk, &P->d_lptr, &P->d_lidx, &P->d_cont,
+                      &P->d_err2, &P->d_synd2, &P->d_dec2, &P->d_llr2, &P->d_list2, &P->d_count2, &P->d_cold2})
         b->release();
     delete P;
 }

@@ -451,8 +451,8 @@ __global__ __launch_bounds__(64, (CPL > 6) ? 1 : 2) void minsum_wave_kernel(Wave
 }
 
 // ------------------------------------------------------------------------------------------ host side
-static std::atomic<int> g_opt_kernel{0}, g_opt_cpl{0}, g_opt_rst{0}, g_opt_grid{0}, g_opt_first{1};
-int mc_first_choice() { return g_opt_first.load(); }
+// shape switches of this kernel (qldpc_set_option, options.hip)
+std::atomic<int> g_opt_wave_cpl{0}, g_opt_wave_rst{0}, g_opt_wave_grid{0};
 
 struct WavePlan { int cpl, vb, rst, LPS, SPW, team_bytes, offV, offM; size_t lds; int waves_per_cu; };
 
@@ -464,7 +464,7 @@ static bool plan_wave(const qldpc_graph *g, WavePlan &P) {
     const int nq = (g->n + 3) / 4;
     static const int cands[][2] = {{6, 3}, {5, 3}, {9, 5}, {4, 2}};       // instantiated (CPL, VB) pairs
     double best = -1.0;
-    const int force_cpl = g_opt_cpl.load(), force_rst = g_opt_rst.load();
+    const int force_cpl = g_opt_wave_cpl.load(), force_rst = g_opt_wave_rst.load();
     for (const auto &cd : cands) {
         const int cpl = cd[0], vb = cd[1];
         if (force_cpl && cpl != force_cpl) continue;
@@ -488,11 +488,9 @@ static bool plan_wave(const qldpc_graph *g, WavePlan &P) {
     return best > 0.0;
 }
 
-int wave_kernel_choice() { return g_opt_kernel.load(); }
-
 bool wave_supported(const qldpc_graph *g, double damping, bool clean) {
     WavePlan P;
-    if (g_opt_kernel.load() == 1) return false;
+    if (wave_kernel_choice() == 1) return false;
     return clean && damping == 1.0 && plan_wave(g, P);
 }
 
@@ -531,7 +529,7 @@ static void fill_wave(const qldpc_graph *g, const WavePlan &P, WaveArgs &A, int6
 
 static unsigned wave_grid(const WavePlan &P, int64_t B) {
     const int64_t groups = (B + P.SPW - 1) / P.SPW;
-    const int per_cu = g_opt_grid.load() > 0 ? g_opt_grid.load() : P.waves_per_cu;
+    const int per_cu = g_opt_wave_grid.load() > 0 ? g_opt_wave_grid.load() : P.waves_per_cu;
     const int64_t cap = (int64_t)256 * per_cu;               // persistent: exactly the waves the chip holds at once
     return (unsigned)std::max<int64_t>(1, std::min(groups, cap));
 }
@@ -559,19 +557,3 @@ int mc_wave_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int m
 
 }  // namespace qldpc
 
-// Process-wide tuning switches for tools/ and the parity tests (results never depend on them; the defaults are what bench.py measures):
-//   "regular_kernel"  0 = automatic, 1 = the 72-thread-team kernel (minsum_regular.hip), 2 = the wave-private kernel where eligible
-//   "wave_cpl"        checks per lane of the wave-private kernel (0 = automatic; 4, 5, 6, 9)
-//   "wave_rst"        row stride of its message buffer in doubles (0 = automatic; 6, 7)
-//   "wave_grid"       waves per CU of its persistent grid (0 = automatic)
-QLDPC_EXPORT int qldpc_set_option(const char *name, int value) {
-    QLDPC_REQUIRE(name != nullptr, "name is NULL");
-    if (!std::strcmp(name, "regular_kernel")) { QLDPC_REQUIRE(value >= 0 && value <= 2, "regular_kernel: 0, 1 or 2"); qldpc::g_opt_kernel = value; return QLDPC_OK; }
-    if (!std::strcmp(name, "wave_cpl")) { QLDPC_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6 || value == 9, "wave_cpl: 0, 4, 5, 6 or 9"); qldpc::g_opt_cpl = value; return QLDPC_OK; }
-    if (!std::strcmp(name, "wave_rst")) { QLDPC_REQUIRE(value == 0 || value == 6 || value == 7, "wave_rst: 0, 6 or 7"); qldpc::g_opt_rst = value; return QLDPC_OK; }
-    if (!std::strcmp(name, "wave_grid")) { QLDPC_REQUIRE(value >= 0 && value <= 32, "wave_grid: 0 .. 32"); qldpc::g_opt_grid = value; return QLDPC_OK; }
-    if (!std::strcmp(name, "mc_first_iteration")) { QLDPC_REQUIRE(value == 0 || value == 1, "mc_first_iteration: 0 or 1"); qldpc::g_opt_first = value; return QLDPC_OK; }
-    if (!std::strcmp(name, "mc_first_bits")) { QLDPC_REQUIRE(value == 8 || value == 16 || value == 32, "mc_first_bits: 8, 16 or 32"); qldpc::mc_first_set_bits(value); return QLDPC_OK; }
-    qldpc::set_error("unknown option '%s'", name);
-    return QLDPC_ERR_INVALID;
-}

@@ -336,7 +336,12 @@ __global__ __launch_bounds__(1024) void minsum_wg_lean_kernel(WgArgs A) {
             long long tq = OSD_CLOCK();
             if (A.fixed || !done) {
                 const double alpha = (it < max_iter) ? A.alpha[it] : 0.0;
-                if (!DAMP && A.edge_lanes) {
+#ifdef QLDPC_EXPERIMENTS
+                const bool x_edge_lanes = A.edge_lanes;
+#else
+                constexpr bool x_edge_lanes = false;
+#endif
+                if (!DAMP && x_edge_lanes) {
                     // SURVEY 7-6 option B, kept as a measured alternative: a check is owned by 16 lanes (lane = edge k, k + 16, k + 32), the row's
                     // min1 / min2 / first-argmin come from a 4-step shuffle butterfly, sign bits and the parity from ballots.  The reduction
                     // (value, index) -> smallest value, then smallest index reproduces "first strict minimum" (kernels.py:301-306); min2 is
@@ -569,6 +574,12 @@ int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, cons
     A.ell_col = natural ? g->d_ell_col : g->d_ell_col_s;
     A.ell_var = natural ? g->d_ell_var : g->d_ell_var_s;
     A.indptr = g->d_indptr; A.indices = g->d_indices;
+#ifndef QLDPC_EXPERIMENTS
+    if (flags & (QLDPC_FLAG_WG_EDGE_LANES | QLDPC_FLAG_WG_IDXLOAD)) {
+        set_error("this decoder variant (flags %#x) is a measured-and-rejected experiment: it exists in libqldpc_hip_experiments.so only (make experiments)", flags);
+        return QLDPC_ERR_UNSUPPORTED;
+    }
+#endif
     A.edge_lanes = ((flags & QLDPC_FLAG_WG_EDGE_LANES) && g->max_row_deg <= 48) ? 1 : 0;
     A.B = B; A.synd = d_synd; A.prior = d_prior; A.alpha = d_alpha; A.clip = clip;
     A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;

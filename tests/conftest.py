@@ -38,6 +38,25 @@ def oracle():
     return orc
 
 
+def experiments_lib():
+    """Bindings of libqldpc_hip_experiments.so (same ABI + the measured-and-rejected kernels): a second copy of the package, imported under the
+    name qldpc_amd_x so that its _lib module can point at the other build.  Graph handles and plans belong to the library that made them."""
+    import importlib.util
+    if "qldpc_amd_x" not in sys.modules:
+        root = os.path.join(ROOT, "qldpc-branched-off_amd")
+        spec = importlib.util.spec_from_file_location("qldpc_amd_x", os.path.join(root, "__init__.py"), submodule_search_locations=[root])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["qldpc_amd_x"] = mod
+        spec.loader.exec_module(mod)
+        mod._lib.select_build("experiments")
+    return sys.modules["qldpc_amd_x"]._lib
+
+
+def package_of(L):
+    """the package copy a bindings module belongs to (qldpc_amd or qldpc_amd_x)"""
+    return sys.modules[L.__name__.rsplit(".", 1)[0]]
+
+
 def assert_llr_close(a, b, tol=1e-5):
     """LLR comparison of the north-star contract: |a-b| <= tol, equal infinities equal, NaN==NaN."""
     a = np.asarray(a, np.float64)

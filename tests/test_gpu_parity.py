@@ -11,7 +11,7 @@ try:            # this image carries two HIP runtimes (system ROCm and the one b
 except ImportError:
     torch = None
 
-from conftest import ROOT, assert_llr_close
+from conftest import ROOT, assert_llr_close, experiments_lib, package_of
 
 pytestmark = pytest.mark.gpu
 LLR_TOL = 1e-5
@@ -26,6 +26,32 @@ def L():
         __graft_entry__.build()
     _lib.require_device()
     return _lib
+
+
+@pytest.fixture(scope="module")
+def LX(L):
+    """libqldpc_hip_experiments.so: the same ABI plus the measured-and-rejected kernels (make -C csrc experiments)"""
+    X = experiments_lib()
+    if not os.path.exists(X.SO_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    X.require_device()
+    return X
+
+
+# kernel variants that exist in the experiments build only (include/qldpc_hip.h); the product library refuses them
+XFLAGS = 0x2 | 0x40000 | 0x4 | 0x8 | 0x10000 | 0x1000 | 0x2000      # WG_EDGE_LANES, WG_IDXLOAD, OSD_PIPED, OSD_P2WAVES, OSD_P3SERIAL, OSD_NOKILL, OSD_FWD
+
+
+def for_build(L, variants, key=lambda v: v):
+    """the kernel variants a build is asked for: the product library everything but the experiments, the experiments build only those"""
+    x = L.BUILD == "experiments"
+    return [v for v in variants if bool(key(v) & XFLAGS) == x]
+
+
+@pytest.fixture(params=["product", "experiments"])
+def Lb(request, L):
+    return L if request.param == "product" else request.getfixturevalue("LX")
 
 
 KERNELS = {"regular": 0x20, "generic": 0x20 | 0x40, "stream": 0x10}   # "regular" falls back to generic on irregular graphs
@@ -85,9 +111,10 @@ def test_bb_golden(L, golden, tag, kern):
 
 
 @pytest.mark.parametrize("tag", ["circ72", "circ144"])
-def test_circuit_level_golden(L, golden, oracle, tag):
+def test_circuit_level_golden(Lb, golden, oracle, tag):
+    L = Lb
     from qldpc_amd.data import load_circuit_matrices
-    from qldpc_amd.decoding.osd import performOSD_enhanced
+    performOSD_enhanced = package_of(L).decoding.osd.performOSD_enhanced
     import scipy.sparse as sp
     g = golden(tag + "_decode")
     data = load_circuit_matrices(tag)
@@ -95,11 +122,11 @@ def test_circuit_level_golden(L, golden, oracle, tag):
         ip, ix = data[f"Hdec{s}_indptr"], data[f"Hdec{s}_indices"]
         m, n = (int(x) for x in data[f"Hdec{s}_shape"])
         graph = L.Graph(ip, ix, n)
-        for fl in (0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM):      # auto = workgroup-per-shot kernel; streaming kernel forced
+        for fl in for_build(L, (0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM)):      # auto = workgroup-per-shot kernel; streaming kernel forced
             check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), fl), g, s)
         # the generic (any-input) workgroup kernel and the natural row / column order must agree with the lean, degree-sorted default
-        for fl in (L.FLAG_WG_GENERIC, L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC | L.FLAG_WG_ROWMAJOR, L.FLAG_WG_EDGE_LANES, L.FLAG_WG_EDGE_LANES | L.FLAG_FIXED_ITERS,
-                       L.FLAG_WG_IDXLOAD, L.FLAG_WG_IDXLOAD | L.FLAG_FIXED_ITERS):     # (default for m <= 1024: column indices resident in registers)
+        for fl in for_build(L, (L.FLAG_WG_GENERIC, L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC | L.FLAG_WG_ROWMAJOR, L.FLAG_WG_EDGE_LANES, L.FLAG_WG_EDGE_LANES | L.FLAG_FIXED_ITERS,
+                                L.FLAG_WG_IDXLOAD, L.FLAG_WG_IDXLOAD | L.FLAG_FIXED_ITERS)):     # (default for m <= 1024: column indices resident in registers)
             check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), fl), g, s)
         rng = np.random.default_rng(5)                                 # ragged random batch, both kernels, vs the oracle
         synd = (rng.random((37, m)) < 0.1).astype(np.int8)
@@ -121,7 +148,7 @@ def test_circuit_level_golden(L, golden, oracle, tag):
             assert np.array_equal(sol2, ref2)
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
             # the general global-memory OSD kernel (used when m > 1024) must agree with the LDS-resident one
-            for kfl in (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_P2WAVES, L.FLAG_OSD_P3SERIAL):   # ... and the other forms of the LDS kernel
+            for kfl in for_build(L, (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_P2WAVES, L.FLAG_OSD_P3SERIAL)):   # ... and the other forms of the LDS kernel
                 sol3 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, flags=kfl)
                 sol4 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0,
                                            ordering=g[f"{s}_osd_ordering"][t], flags=kfl)
@@ -335,7 +362,7 @@ def test_code_capacity_tally_matches_oracle(L, oracle):
 def options(L):
     """qldpc_set_option switches are process-wide: put the defaults back after a test that turns them"""
     yield L.set_option
-    for name, v in (("regular_kernel", 0), ("wave_cpl", 0), ("wave_rst", 0), ("wave_grid", 0), ("mc_first_iteration", 1), ("mc_first_bits", 8)):
+    for name, v in (("mc_first_iteration", 1), ("mc_first_bits", 8), ("mc_tail_overlap", 1)):
         L.set_option(name, v)
 
 
@@ -372,7 +399,9 @@ def test_first_iteration_pipeline_equals_full_decoder_and_oracle(L, oracle, opti
     assert np.array_equal(L.cc_sample_decode_tally(graph, c["Lx"], 0.05, 5, 0, 3000, max_iter=50), ref)
 
 
-def test_wave_private_kernel_matches_golden_and_team_kernel(L, golden, oracle, options):
+def test_wave_private_kernel_matches_golden_and_team_kernel(LX, golden, oracle):
+    L = LX
+    options = L.set_option
     """csrc/minsum_wave.hip (option regular_kernel = 2): a team of lanes of one wave per shot, no workgroup barrier.  Bit-identical to the
     reference fixtures in decode mode (clean inputs; everything else must still take the team kernel) and identical tallies in the fused
     Monte-Carlo mode, fixed-work and early-exit, for every instantiated shape."""
@@ -415,6 +444,30 @@ def test_wave_private_kernel_matches_golden_and_team_kernel(L, golden, oracle, o
         for fl in (0, L.FLAG_FIXED_ITERS):
             for a, b in zip(decode(L, graph, synd, prior, 20, fl), ref):
                 assert np.array_equal(a, b, equal_nan=True)
+    for name in ("regular_kernel", "wave_cpl", "wave_rst", "wave_grid"):
+        options(name, 0)
+
+
+def test_product_library_refuses_the_experiments(L, oracle):
+    """Measured-and-rejected kernels live in libqldpc_hip_experiments.so only: the product library answers their flags and options with
+    QLDPC_ERR_UNSUPPORTED instead of silently running something else."""
+    from qldpc_amd.data import load_code, load_circuit_matrices
+    d = load_circuit_matrices("circ72")
+    n = int(d["HdecZ_shape"][1])
+    graph = L.Graph(d["HdecZ_indptr"], d["HdecZ_indices"], n)
+    synd = np.zeros((2, int(d["HdecZ_shape"][0])), np.int8)
+    prior = np.full(n, 3.0)
+    for fl in (L.FLAG_WG_EDGE_LANES, L.FLAG_WG_IDXLOAD):
+        with pytest.raises(L.QldpcError, match="experiment"):
+            L.minsum_decode_batch(graph, synd, prior, 5, "dynamical", 1.0, flags=fl)
+    for fl in (L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_P2WAVES | L.FLAG_OSD_LDS, L.FLAG_OSD_P3SERIAL | L.FLAG_OSD_LDS, L.FLAG_OSD_NOKILL | L.FLAG_OSD_LDS):
+        with pytest.raises(L.QldpcError, match="experiment"):
+            L.osd0_batch(graph, synd, np.ones((2, n)), np.zeros((2, n), np.int8), flags=fl)
+    with pytest.raises(L.QldpcError, match="experiment"):
+        L.set_option("regular_kernel", 2)
+    L.set_option("regular_kernel", 0)
+    with pytest.raises(L.QldpcError, match="unknown option"):
+        L.set_option("no_such_switch", 1)
 
 
 def test_philox_known_answer(L, oracle):
@@ -907,7 +960,7 @@ def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch
             from scipy.sparse import csr_matrix
             H = csr_matrix((np.ones(len(ix), np.int8), ix, ip), shape=(len(ip) - 1, n))
             for t, case in enumerate(g[f"{s}_osd_cases"]):
-                for kfl in (L.FLAG_OSD_UG, L.FLAG_OSD_UG | L.FLAG_OSD_FWD):
+                for kfl in (L.FLAG_OSD_UG,):
                     sol = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, ordering=g[f"{s}_osd_ordering"][t],
                                               flags=kfl)
                     assert np.array_equal(sol, g[f"{s}_osd_solution"][t]), (tag, s, t, kfl)
@@ -937,10 +990,11 @@ def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch
                 assert np.array_equal(oracle.syndrome_check(ip, ix, sol[b]), synd[b])
 
 
-def test_random_irregular_graphs_all_kernels(L, oracle, monkeypatch):
+def test_random_irregular_graphs_all_kernels(Lb, oracle, monkeypatch):
     """Differential sweep over seeded random Tanner graphs (ragged degrees, empty rows, isolated and degree-1 columns, duplicate rows) of
     sizes that select every decoder: resident (small), workgroup-per-shot generic / lean in LDS and with posteriors in HBM/L2, streaming;
     random alpha mode, iteration cap, clip, damping and priors (some zero, some negative).  Everything bit-identical to the oracle."""
+    L = Lb
     rng = np.random.default_rng(2026)
     shapes = [(5, 9, 3), (12, 30, 4), (40, 90, 5), (64, 200, 7), (150, 600, 6), (300, 2100, 9), (700, 5000, 12), (1100, 9000, 20)]
     ran = {"vg": 0, "stream": 0}
@@ -973,17 +1027,18 @@ def test_random_irregular_graphs_all_kernels(L, oracle, monkeypatch):
             if n >= 2000:
                 variants.append((L.FLAG_WG_VGLOBAL, "1"))              # posteriors in global memory
                 variants.append((L.FLAG_WG_VGLOBAL | L.FLAG_WG_ROWMAJOR, "1"))
-            for flags, vg in variants:
+            for flags, vg in for_build(L, variants, key=lambda v: v[0]):
                 if vg:
                     ran["vg"] += 1
                 out = L.minsum_decode_batch(graph, synd, prior, iters, mode, alpha, damping=damping, clip_llr=clip, flags=flags)
                 ran["stream"] += flags == L.FLAG_KERNEL_STREAM
                 for name, a, b in zip(("err", "conv", "llr", "iter"), (out[0], out[1].astype(bool), out[2], out[3]), (ref[0], ref[1].astype(bool), ref[2], ref[3])):
                     assert np.array_equal(a, b, equal_nan=True), (gi, trial, flags, vg, name, mode, damping, clip, iters)
-    assert ran["vg"] >= 6 and ran["stream"] >= 20
+    assert L.BUILD == "experiments" or (ran["vg"] >= 6 and ran["stream"] >= 20)
 
 
-def test_degree_one_checks_and_nan_posteriors(L, oracle):
+def test_degree_one_checks_and_nan_posteriors(Lb, oracle):
+    L = Lb
     """Degree-1 checks emit +-inf messages (kernels.py:301-314 with min2 = inf) and the next iteration turns inf - inf into 0 (kernels.py:328).
     (a) every column meets at most one of them: only the waves that hold such rows run the NaN test; (b) a column meets TWO with opposite
     syndromes: its posterior is NaN and every kernel must carry the NaN exactly like the reference.  Workgroup-per-shot kernels (register-
@@ -1007,13 +1062,14 @@ def test_degree_one_checks_and_nan_posteriors(L, oracle):
         ref = oracle.minsum_decode_batch(ip, ix, n, synd, prior, max_iter=9)
         if variant == "two_on_a_column":
             assert np.isnan(ref[2]).any()
-        for fl in (0, L.FLAG_FIXED_ITERS, L.FLAG_WG_IDXLOAD, L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC, L.FLAG_KERNEL_STREAM):
+        for fl in for_build(L, (0, L.FLAG_FIXED_ITERS, L.FLAG_WG_IDXLOAD, L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC, L.FLAG_KERNEL_STREAM)):
             out = L.minsum_decode_batch(graph, synd, prior, 9, "dynamical", 1.0, flags=fl)
             for name, a, b in zip(("err", "conv", "llr", "iter"), (out[0], out[1].astype(bool), out[2], out[3]), (ref[0], ref[1].astype(bool), ref[2], ref[3])):
                 assert np.array_equal(a, b, equal_nan=True), (variant, fl, name)
 
 
-def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
+def test_random_matrices_osd0_all_kernels(Lb, oracle, monkeypatch):
+    L = Lb
     """Differential sweep of OSD-0 over seeded random matrices (dependent rows, empty rows, heavy and empty columns, ties in |llr|,
     realisable and unrealisable syndromes) through its kernels: the one-wave literal elimination (small matrices), the row transform in LDS
     (round-1 and round-2 forms of its phases), in HBM/L2 (forced), the forward and pipelined variants, and the global-memory elimination (forced).
@@ -1038,8 +1094,8 @@ def test_random_matrices_osd0_all_kernels(L, oracle, monkeypatch):
         hard = (rng.random((B, n)) < 0.1).astype(np.int8)
         want = np.stack([oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)])
         # (0 = the one-wave literal elimination for m <= 128, n <= 1024, else the transform kernel; FLAG_OSD_LDS forces the latter)
-        for env in (0, L.FLAG_OSD_LDS, L.FLAG_OSD_LDS | L.FLAG_OSD_P2WAVES, L.FLAG_OSD_LDS | L.FLAG_OSD_P3SERIAL, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD,
-                    L.FLAG_OSD_PIPED, L.FLAG_OSD_NOKILL):
+        for env in for_build(L, (0, L.FLAG_OSD_LDS, L.FLAG_OSD_LDS | L.FLAG_OSD_P2WAVES, L.FLAG_OSD_LDS | L.FLAG_OSD_P3SERIAL, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD,
+                                 L.FLAG_OSD_PIPED, L.FLAG_OSD_NOKILL)):
             sol = L.osd0_batch(graph, synd, llr, hard, flags=env)
             assert np.array_equal(sol, want), (gi, env, np.flatnonzero((sol != want).any(1)))
 

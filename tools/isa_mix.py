@@ -279,7 +279,47 @@ def analyse(src, pattern, loop_pick=None):
     return res
 
 
+# the kernels bench.py prices: key -> (source file, kernel name pattern, which loop: None = the innermost loop with most VALU instructions,
+# "whole" = the whole kernel body (kernels whose time is spread over many loops), files whose text fixes the instruction stream)
+RECORDED = {
+    "cc_bb144_fixed": ("minsum_regular.hip", "minsum_regular_kernel<6, 3, false, true, true, true>", None, ["minsum_regular.hip", "minsum_common.h", "minsum_f64.h", "mc_common.h"]),
+    "cc_bb144_early_exit": ("mc_first.hip", "mc_first_kernel<8, 6, 3>", None, ["mc_first.hip", "mc_common.h"]),
+    "circ144_bp": ("minsum_wg.hip", "minsum_wg_lean_kernel<true, false, false, true>", "whole", ["minsum_wg.hip", "minsum_common.h"]),
+    "circ144_osd": ("gf2.hip", "osd0_lds_kernel<false>", "whole", ["gf2.hip", "osd_common.h"]),
+}
+
+
+def digest(files):
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def record(path):
+    out = {"rates": "profiles/r03_issue_rate.txt (tools/microbench/issue_rate.hip on the GPU box)", "entries": {}}
+    for key, (src, pat, which, files) in RECORDED.items():
+        r = analyse(src, pat)
+        if which == "whole" or "steady_state" not in r:
+            m, scope = r["whole"], "whole kernel (static)"
+        else:
+            m, scope = r["steady_state"]["mix"], f"steady-state loop [{r['steady_state']['first']}..{r['steady_state']['last']}] (static)"
+        valu = sum(k for c, k in m.items() if c.startswith("valu_"))
+        cyc = weighted(m)
+        out["entries"][key] = {"kernel": r["kernel"], "scope": scope, "mix": m, "valu_instructions": valu, "valu_issue_cycles": cyc,
+                               "cycles_per_valu_instruction": round(cyc / max(valu, 1), 4), "code_object": r["meta"],
+                               "sources": files, "source_digest": digest(files)}
+        print(f"{key:22s} {r['kernel'][:60]:60s} {scope:46s} VALU {valu:5d}  issue cycles {cyc:6d}  -> {cyc / max(valu, 1):.3f} cycles per instruction; {r['meta']}")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
 def main():
+    if len(sys.argv) >= 2 and sys.argv[1] == "--record":
+        record(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "isa_mix.json"))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("source")
     ap.add_argument("kernel")

@@ -24,7 +24,10 @@ ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
 ap.add_argument("--serial", action="store_true", help="both sectors on one stream (QLDPC_FLAG_MC_UNFUSED): per-phase times are then exclusive")
 ap.add_argument("--reps", type=int, default=1)
 ap.add_argument("--cpu-trials", type=int, default=0, help="also time the CPU checker (C port of the reference loop, all host threads) on this many trials")
+ap.add_argument("--timers", action="store_true", help="load libqldpc_hip_timers.so (make -C csrc timers): in-kernel phase counters")
 a = ap.parse_args()
+if a.timers:
+    _lib.select_build("timers")
 d = load_circuit_matrices(a.tag)
 c = load_code(str(d["code"]))
 cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=int(d["num_cycles"]), ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"],

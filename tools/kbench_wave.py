@@ -12,6 +12,8 @@ import qldpc_amd  # noqa: F401,E402
 from qldpc_amd import _lib  # noqa: E402
 from qldpc_amd.data import load_code  # noqa: E402
 
+_lib.select_build("experiments")          # the wave-private kernel lives in libqldpc_hip_experiments.so (make -C csrc experiments)
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--code", default="bb144")
 ap.add_argument("--batch", type=int, default=1 << 20)

@@ -191,7 +191,7 @@ while time.time() < t_end:
         if rng.random() < 0.5:
             llr = np.round(llr)
         hard = (rng.random((B, n)) < 0.01).astype(np.int8)
-        variants = [0, 0, L.FLAG_OSD_UG, L.FLAG_OSD_FWD, L.FLAG_OSD_NOKILL] + ([L.FLAG_OSD_GLOBAL] if tag == "circ72" else [])
+        variants = [0, 0, L.FLAG_OSD_UG, L.FLAG_OSD_LDS] + ([L.FLAG_OSD_GLOBAL] if tag == "circ72" else [])
         env = int(rng.choice(variants))
         sol = L.osd0_batch(g, synd, llr, hard, flags=env)
         for b in range(B):
