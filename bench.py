@@ -55,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=1 << 20, help="shots per step per GPU (BASELINE config 2 is quoted at 4096)")
     ap.add_argument("--code", default="bb144", help="bb72 = BASELINE config 2, bb144 = config 3 (headline), bb288 = config 4")
     ap.add_argument("--p", type=float, default=0.005)
+    ap.add_argument("--p-sweep", default="", help="comma-separated error rates (BASELINE config 4: --code bb288 --p-sweep 0.004,0.005,0.006): the headline leg once "
+                                                  "per point, one tally and one all-reduce per point, every point in the JSON line; `value` is the rate over all points")
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per baseline (each of the two legs)")
@@ -274,6 +276,14 @@ def worker(args):
             dist.all_reduce(td, op=dist.ReduceOp.MAX)
         return float(td.item())
 
+    def every_rank(x):
+        """[x of rank 0, x of rank 1, ...] on every rank (attribution of a scaling loss: which rank was slow)"""
+        if world == 1:
+            return [float(x)]
+        parts = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(parts, torch.tensor([x], dtype=torch.float64, device=coll_dev))
+        return [float(t.item()) for t in parts]
+
     out = {}
     # ============================================================ code capacity (BASELINE configs 2-4; headline = config 3) ============
     if not args.no_code_capacity:
@@ -285,8 +295,11 @@ def worker(args):
         B, K, W = args.batch, args.steps, args.warmup
         b_io = m + n + 8 * n + 5
 
-        def run_leg(flags):
-            plan = _lib.CodeCapacityPlan(graph, code["Lx"], args.p, max_iter=args.max_iter, use_osd=True, flags=flags | kflag | _lib.FLAG_CLOCK_PROBE,
+        leg_extra = {}
+
+        def run_leg(flags, p=None, tag="fixed"):
+            p = args.p if p is None else p
+            plan = _lib.CodeCapacityPlan(graph, code["Lx"], p, max_iter=args.max_iter, use_osd=True, flags=flags | kflag | _lib.FLAG_CLOCK_PROBE,
                                          batch=B)
 
             def shot0(step):          # disjoint global shot ranges: step-major, then rank
@@ -300,9 +313,14 @@ def worker(args):
             for k in range(K):
                 plan.run(SEED, shot0(k), B, stream)
             tally = plan.read(stream)             # synchronises the stream
+            t_local = time.perf_counter() - t0    # this rank's own time to finish its K steps
+            t1 = time.perf_counter()
             total = reduce_tally(tally)           # the one collective of the path (replaces engine.py:450-457)
+            t_coll = time.perf_counter() - t1     # includes waiting for the slowest rank
             barrier()
             dt = time.perf_counter() - t0
+            leg_extra[tag] = {"per_rank_ms_per_step": [round(x / K * 1e3, 4) for x in every_rank(t_local)],
+                              "tally_allreduce_ms": [round(x * 1e3, 4) for x in every_rank(t_coll)]}
             ms_first = plan.first_iteration_time()
             ms_k, launches = plan.kernel_time()
             try:
@@ -312,11 +330,18 @@ def worker(args):
             plan.close()
             return max_over_ranks(dt), total, tally, ms_k, launches, clock, ms_first
 
+        sweep = [float(x) for x in args.p_sweep.split(",") if x] if args.p_sweep else []
+        sweep_points = []
+        for ps in sweep:                          # BASELINE config 4: one tally and one all-reduce per error rate
+            dt_p, tot_p, _, ms_p, nl_p, _, _ = run_leg(_lib.FLAG_FIXED_ITERS, p=ps, tag=f"p={ps:g}")
+            sweep_points.append({"p": ps, "value": round(world * K * B / dt_p, 1), "unit": "shots/s", "ms_per_step": round(dt_p / K * 1e3, 4),
+                                 "kernel_ms_per_launch": round(ms_p / max(nl_p, 1), 4), "logical_error_rate": round(float(tot_p[T["total_err"]]) / max(1, int(tot_p[T["trials"]])), 8),
+                                 "tally": {k: int(tot_p[v]) for k, v in T.items() if k.endswith("_z") or k in ("trials", "total_err")}, **leg_extra[f"p={ps:g}"]})
         dt_fixed, tally_fixed, local_fixed, ms_fixed, nl_fixed, clk_fixed, _ = run_leg(_lib.FLAG_FIXED_ITERS)
         if args.legs == "fixed":
             dt_ref, tally_ref, ms_ref, nl_ref, clk_ref, ms_first = dt_fixed, tally_fixed, ms_fixed, nl_fixed, clk_fixed, 0.0
         else:
-            dt_ref, tally_ref, _, ms_ref, nl_ref, clk_ref, ms_first = run_leg(0)
+            dt_ref, tally_ref, _, ms_ref, nl_ref, clk_ref, ms_first = run_leg(0, tag="reference_semantics")
         if not np.array_equal(tally_fixed, tally_ref):
             raise SystemExit(f"fixed-work and early-exit legs disagree: {tally_fixed.tolist()} vs {tally_ref.tolist()}")
         shots_total = world * K * B
@@ -374,7 +399,15 @@ def worker(args):
                                                                            "clock_mhz": round(clk_ref, 1) if clk_ref else None,
                                                                            "hbm_model": hbm_model(bytes_ref, ms_ref, nl_ref)}},
             "tally": {k: int(tally_ref[v]) for k, v in T.items() if k.endswith("_z") or k in ("trials", "total_err")},
+            "per_rank": leg_extra.get("fixed"),
         })
+        if "reference_semantics" in leg_extra and "reference_semantics" in out:
+            out["reference_semantics"]["per_rank"] = leg_extra["reference_semantics"]
+        if sweep_points:
+            tot_shots = sum(world * K * B for _ in sweep_points)
+            tot_time = sum(pt["ms_per_step"] * K / 1e3 for pt in sweep_points)
+            out["p_sweep"] = {"points": sweep_points, "value": round(tot_shots / tot_time, 1), "unit": "shots/s",
+                              "note": "BASELINE config 4 shape: fixed-work leg per error rate, one tally + one all-reduce per point"}
         if args.legs == "fixed":
             del out["reference_semantics"]
 

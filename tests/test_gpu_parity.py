@@ -114,7 +114,8 @@ def test_bb_golden(L, golden, tag, kern):
 def test_circuit_level_golden(Lb, golden, oracle, tag):
     L = Lb
     from qldpc_amd.data import load_circuit_matrices
-    performOSD_enhanced = package_of(L).decoding.osd.performOSD_enhanced
+    import importlib
+    performOSD_enhanced = importlib.import_module(package_of(L).__name__ + ".decoding.osd").performOSD_enhanced
     import scipy.sparse as sp
     g = golden(tag + "_decode")
     data = load_circuit_matrices(tag)
@@ -1281,7 +1282,7 @@ def test_bench_starts_its_own_ranks(L, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["QLDPC_BENCH_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "65536",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "65536", "--p-sweep", "0.004,0.006",
                         "--circuit", "circ72", "--circuit-batch", "1024", "--circuit-steps", "2", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -1292,6 +1293,8 @@ def test_bench_starts_its_own_ranks(L, tmp_path):
     assert out["tally"]["trials"] == 2 * 2 * 65536                    # world x steps x batch shots went through the all-reduce
     assert out["circuit_level"]["tally"]["trials"] == 2 * 2 * 1024
     assert out["value"] > 0 and out["circuit_level"]["value"] > 0
+    assert [pt["p"] for pt in out["p_sweep"]["points"]] == [0.004, 0.006] and all(pt["tally"]["trials"] == 2 * 2 * 65536 for pt in out["p_sweep"]["points"])
+    assert len(out["per_rank"]["per_rank_ms_per_step"]) == 2 and len(out["per_rank"]["tally_allreduce_ms"]) == 2
     # the same shots on one rank give the same tally (the Philox streams are keyed by the global shot index)
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "65536",
                          "--circuit", "circ72", "--circuit-batch", "1024", "--circuit-steps", "4", "--no-cpu-baseline"],
@@ -1321,6 +1324,117 @@ def test_native_rccl_tally_allreduce(L):
     c2.close()
     with pytest.raises(L.QldpcError):
         L.Comm.init_all(L.device_count() + 1)
+
+
+def _two_gpus(L):
+    return L.device_count() >= 2
+
+
+def _nccl_rank(rank, world, port, out_dir):
+    """one rank of the real N > 1 path: its own GPU, torch.distributed 'nccl' (= RCCL), shot range sharded, one all-reduce of the tally"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd import _lib, parallel
+    from qldpc_amd.data import load_code
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    c = load_code("bb144")
+    graph = _lib.Graph(c["Hx_indptr"], c["Hx_indices"], c["n"], device=rank)
+    t = parallel.run_code_capacity(graph, c["Lx"], 0.03, 4242, 30001, max_iter=50, device=rank)
+    np.save(os.path.join(out_dir, f"nccl_tally_{rank}.npy"), t)
+    assert torch.cuda.current_device() == rank                          # the entry points put the caller's device back
+    dist.destroy_process_group()
+
+
+def test_two_gpus_torch_nccl_sharded_tally(L, oracle, tmp_path):
+    """(e) on hardware: two ranks, two cards, RCCL through torch.distributed.  Skips on a one-GPU box (this pool's); runs the day two are visible."""
+    if not _two_gpus(L):
+        pytest.skip("needs two GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    from qldpc_amd.data import load_code
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_nccl_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    c = load_code("bb144")
+    ref = oracle.cc_sample_decode_tally(c["Hx_indptr"], c["Hx_indices"], c["n"], c["Lx"], 0.03, 4242, 0, 30001, max_iter=50, threads=0)
+    for r in range(2):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), f"nccl_tally_{r}.npy")), ref)
+
+
+def _native_rank(rank, world, uid_path, out_dir):
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import qldpc_amd  # noqa: F401
+    from qldpc_amd import _lib
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if rank == 0:
+        uid = _lib.Comm.unique_id()
+        with open(uid_path + ".tmp", "wb") as fh:
+            fh.write(uid)
+        os.replace(uid_path + ".tmp", uid_path)
+    else:
+        for _ in range(600):
+            if os.path.exists(uid_path):
+                break
+            time.sleep(0.1)
+        with open(uid_path, "rb") as fh:
+            uid = fh.read()
+    comm = _lib.Comm.init_rank(world, rank, uid, rank)
+    t = (np.arange(16, dtype=np.int64) + 1) * (rank + 1)
+    np.save(os.path.join(out_dir, f"native_{rank}.npy"), comm.allreduce(t))
+    comm.close()
+
+
+def test_two_gpus_native_rccl_communicators(L, tmp_path):
+    """qldpc_comm_init_all(2) in one process and qldpc_comm_init_rank x 2 in two (the launcher-without-PyTorch path), on two cards."""
+    if not _two_gpus(L):
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    comm = L.Comm.init_all(2)
+    assert (comm.nranks, comm.nlocal) == (2, 2)
+    t = np.stack([np.arange(16, dtype=np.int64) + 1, (np.arange(16, dtype=np.int64) + 1) * 10])
+    got = comm.allreduce(t)                                             # one tally per local rank in, the sum on every local rank out
+    assert np.array_equal(got, np.stack([t.sum(0), t.sum(0)]))
+    comm.close()
+    mp.spawn(_native_rank, args=(2, os.path.join(str(tmp_path), "uid.bin"), str(tmp_path)), nprocs=2, join=True)
+    want = (np.arange(16, dtype=np.int64) + 1) * 3
+    for r in range(2):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), f"native_{r}.npy")), want)
+
+
+def test_two_gpus_bench_over_rccl(L):
+    """`python bench.py --gpus 2` on two cards with the default backend (nccl = RCCL): the driver's scaling run in miniature, incl. the p-sweep of
+    BASELINE config 4; tallies equal the one-rank run's."""
+    if not _two_gpus(L):
+        pytest.skip("needs two GPUs")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "QLDPC_BENCH_BACKEND")}
+    outs = []
+    for gpus, steps in ((2, 2), (1, 4)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", str(steps), "--warmup", "1", "--batch", "65536", "--code", "bb288",
+                            "--p-sweep", "0.004,0.006", "--circuit", "circ72", "--circuit-batch", "1024", "--circuit-steps", str(steps), "--no-cpu-baseline"],
+                           env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0]))
+    two, one = outs
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["collective_backend"] == "nccl"
+    assert two["tally"] == one["tally"] and two["circuit_level"]["tally"] == one["circuit_level"]["tally"]
+    assert [pt["tally"] for pt in two["p_sweep"]["points"]] == [pt["tally"] for pt in one["p_sweep"]["points"]]
+    assert len(two["per_rank"]["per_rank_ms_per_step"]) == 2 and len(two["per_rank"]["tally_allreduce_ms"]) == 2
 
 
 def test_run_simulation_osd_order_on_unsatisfiable_trials(L, oracle):

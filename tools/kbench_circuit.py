@@ -23,6 +23,7 @@ ap.add_argument("--no-osd", action="store_true")
 ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
 ap.add_argument("--serial", action="store_true", help="both sectors on one stream (QLDPC_FLAG_MC_UNFUSED): per-phase times are then exclusive")
 ap.add_argument("--reps", type=int, default=1)
+ap.add_argument("--counts-out", default="", help="with --timers: write the OSD-0 workload counts per shot (pivots, columns, touched row updates) as JSON")
 ap.add_argument("--cpu-trials", type=int, default=0, help="also time the CPU checker (C port of the reference loop, all host threads) on this many trials")
 ap.add_argument("--timers", action="store_true", help="load libqldpc_hip_timers.so (make -C csrc timers): in-kernel phase counters")
 a = ap.parse_args()
@@ -78,6 +79,16 @@ for rep in range(a.reps):
             print(f"  [osd timers] shots={h[0]:.0f} chunks/shot={h[1] / h[0]:.2f} cols/shot={h[2] / h[0]:.1f} pivots/shot={h[3] / h[0]:.1f} kills/shot={h[5] / h[0]:.1f} "
                   f"blocks/shot={h[6] / h[0]:.1f} kcycles/shot={h[4] / h[0] / 1e3:.1f} (sort {h[8] / h[0] / 1e3:.0f} p1 {h[9] / h[0] / 1e3:.0f} p2 {h[10] / h[0] / 1e3:.0f} "
                   f"p3 {h[11] / h[0] / 1e3:.0f} kill {h[12] / h[0] / 1e3:.0f} backsub {h[13] / h[0] / 1e3:.0f}; extra counters per shot [7] {h[7] / h[0]:.1f} [14] {h[14] / h[0]:.1f} [15] {h[15] / h[0]:.1f})", flush=True)
+            if a.counts_out:
+                import json
+                mz = int(d["HdecZ_shape"][0])
+                with open(a.counts_out, "w") as fh:
+                    json.dump({"source": f"tools/kbench_circuit.py --timers --tag {a.tag} --trials {a.trials} (diagnostic build, both sectors)", "shots": h[0],
+                               "m": mz, "n": int((int(d["HdecZ_shape"][1]) + int(d["HdecX_shape"][1])) / 2), "mw": (mz + 63) // 64,
+                               "cdeg": int(max(np.diff(d["HdecZ_indptr"]).max() and 6, 6)), "pivots": round(h[3] / h[0], 1), "cols": round(h[2] / h[0], 1),
+                               "blocks": round(h[6] / h[0], 2), "touched": round(h[15] / h[0], 1), "kcycles": round(h[4] / h[0] / 1e3, 1),
+                               "kcycles_by_phase": {"sort": round(h[8] / h[0] / 1e3, 1), "p1": round(h[9] / h[0] / 1e3, 1), "p2": round(h[10] / h[0] / 1e3, 1),
+                                                    "p3": round(h[11] / h[0] / 1e3, 1), "kill": round(h[12] / h[0] / 1e3, 1)}}, fh)
 
 if a.cpu_trials > 0:
     from oracle import oracle as orc            # CPU checker, timed beside the GPU path (never part of it)

@@ -51,19 +51,21 @@ def main():
     with open(os.path.join(src, "workload.json")) as fh:
         wl = json.load(fh)
     counters = {}
-    for p in ("sq_a", "sq_b", "fetch", "write", "grbm"):
+    for p in ("sq_a", "sq_b", "sq_c", "fetch", "write", "grbm"):
         counters.update(load_pass(os.path.join(src, p)))
     cl = wl["circuit_level"]
-    regular = ["minsum_regular.hip", "minsum_common.h", "mc_common.h"]
+    regular = ["minsum_regular.hip", "minsum_common.h", "minsum_f64.h", "mc_common.h"]        # (the same lists as tools/isa_mix.py RECORDED)
     specs = {   # key: (kernel-name match, counted launches, units per launch, unit, sources)
         f"cc_{wl['code']}_fixed": (lambda k: (regular_args(k) or [""] * 6)[4:6] == ["true", "true"], 2,
                                    wl["cc_fixed"]["shots_per_launch"] * wl["cc_fixed"]["max_iter"], "shot_iteration", regular),
-        f"cc_{wl['code']}_early_exit": (lambda k: (regular_args(k) or [""] * 6)[4:6] == ["true", "false"], 2,
-                                        wl["cc_early_exit"]["shots_per_launch"], "shot", regular),
+        # reference semantics: the bit-sliced first iteration sees every shot (the full decoder only the few it lists: cc_..._early_exit_full)
+        f"cc_{wl['code']}_early_exit": (lambda k: "mc_first_kernel" in k, 2, wl["cc_early_exit"]["shots_per_launch"], "shot", ["mc_first.hip", "mc_common.h"]),
+        f"cc_{wl['code']}_early_exit_full": (lambda k: (regular_args(k) or [""] * 6)[4:6] == ["true", "false"], 2,
+                                             wl["cc_early_exit"]["shots_per_launch"], "shot", regular),
         f"{wl['circuit']}_bp": (lambda k: "minsum_wg_lean_kernel" in k, 2, (cl["iters_z"] + cl["iters_x"]) / 2.0, "decode_iteration",
                                 ["minsum_wg.hip", "minsum_common.h"]),
-        f"{wl['circuit']}_osd": (lambda k: "osd0_lds_kernel" in k or "osd0_fwd_kernel" in k, 2, (cl["osd_z"] + cl["osd_x"]) / 2.0, "osd_shot",
-                                 ["gf2.hip", "osd_common.h", "osd_fwd.hip"]),
+        f"{wl['circuit']}_osd": (lambda k: "osd0_lds_kernel" in k, 2, (cl["osd_z"] + cl["osd_x"]) / 2.0, "osd_shot",
+                                 ["gf2.hip", "osd_common.h"]),
     }
     entries, lines = {}, []
     for key, (match, nl, units, unit, sources) in specs.items():
@@ -86,12 +88,32 @@ def main():
             e["lds_bank_conflict_frac"] = round(e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"], 4)
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
-        # algorithmic floors (lane-operations per unit)
+        if e.get("SQ_LDS_IDX_ACTIVE") and e.get("SQ_BUSY_CYCLES"):
+            e["lds_busy_frac"] = round(e["SQ_LDS_IDX_ACTIVE"] / e["SQ_BUSY_CYCLES"] / 4.0, 4)          # LDS-array cycles / (SQ busy cycles x 4 arrays per SE sample)
+        types = {c[len("SQ_INSTS_VALU_"):]: round(e[c] / units, 3) for c in e if c.startswith("SQ_INSTS_VALU_")}
+        if types:
+            e["valu_types"] = types                   # wave-instructions per unit by the hardware's own type counters (cross-check of the static mix)
+        # algorithmic floors in SIMD issue-cycles per unit (lane-operations x cycles of the cheapest instruction / 64)
         if unit == "decode_iteration":
             fl = 0.0
             for dm in cl["dims"]:
-                fl += dm["nnz"] * (11.0 + 14.0 / 6.0) + dm["nonempty_rows"] * 2.0 + dm["nnz"] + dm["n"]
-            e["floor_lane_ops_per_unit"] = round(fl / len(cl["dims"]), 1)
+                # per edge: q = clip(v - r) 3 f64 (12), sign XOR (2), compare + 2 selects + sign insert (16), parity XOR (2) = 32; its share of the
+                # min1 / min2 network (14 / 6 f64 per edge), the variable-side addition (4); per nonempty row two multiplications (8); per column + prior (4)
+                fl += dm["nnz"] * (32.0 + 14.0 / 6.0 * 4.0 + 4.0) + dm["nonempty_rows"] * 8.0 + dm["n"] * 4.0
+            e["floor_issue_cycles_per_unit"] = round(fl / len(cl["dims"]) / 64.0, 1)
+        if unit == "osd_shot" and "osd_counts" in wl:
+            oc = wl["osd_counts"]           # per OSD shot, from the diagnostic build (tools/kbench_circuit.py --timers): pivots, columns through phase 1 / 2, touched (row, operation) pairs
+            mw = oc["mw"]
+            # word = 64 bits = two 32-bit XORs (2 x 2 cycles).  sort: 8 radix passes x 3 cheap operations per key; column reduction: (deg - 1) word-XORs per
+            # word; the block-local elimination: each pivot updates the (15 / 2 on average) later columns of its block; row updates: one bit test per
+            # (row, operation) pair and mw word-XORs per touched pair
+            lane_cycles = (oc["n"] * 8 * 3 * 2.0 + oc["cols"] * (oc["cdeg"] - 1) * mw * 4.0 + oc["pivots"] * 7.5 * mw * 4.0 +
+                           oc["pivots"] * (oc["m"] + 2) * 2.0 + oc["touched"] * mw * 4.0)
+            e["floor_issue_cycles_per_unit"] = round(lane_cycles / 64.0, 1)
+            # critical path: the pivots of a shot are found one after the other; a step is at least a compare/ballot, a scalar find-first, two lane reads,
+            # a second find-first and the broadcast of the mask: ~8 dependent instructions at >= 8 cycles each
+            e["floor_chain_cycles_per_unit"] = round(oc["pivots"] * 64.0, 1)
+            e["osd_counts"] = oc
         entries[key] = e
         per = e["SQ_INSTS_VALU"] / units
         lines.append(f"{key:26s} {e.get('kernel', '?')[:70]:70s} VALU/launch {e['SQ_INSTS_VALU']:.4g}  per {unit} {per:.3f}  "

@@ -24,6 +24,7 @@ ap.add_argument("--code", default="bb144")
 ap.add_argument("--circuit", default="circ144")
 ap.add_argument("--batch", type=int, default=1 << 20)
 ap.add_argument("--circuit-batch", type=int, default=16384)
+ap.add_argument("--osd-counts", default="", help="JSON of tools/kbench_circuit.py --timers --counts-out: OSD-0 workload counts per shot (for its floor)")
 a = ap.parse_args()
 T = _lib.TALLY
 out = {"code": a.code, "circuit": a.circuit}
@@ -61,6 +62,9 @@ t = plan.read()
 out["circuit_level"] = {"batch": a.circuit_batch, "iters_z": int(t[T["iters_z"]]), "iters_x": int(t[T["iters_x"]]), "osd_z": int(t[T["osd_z"]]),
                         "osd_x": int(t[T["osd_x"]]), "dims": dims}
 plan.close()
+if a.osd_counts and os.path.exists(a.osd_counts):
+    with open(a.osd_counts) as fh:
+        out["osd_counts"] = json.load(fh)
 print(json.dumps(out), flush=True)
 if a.out:
     with open(a.out, "w") as fh:
