@@ -502,22 +502,9 @@ def circuit_leg(args, _lib, rank, world, local_rank, stream, barrier, reduce_tal
     total = reduce_tally(tally)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
-    phases_overlapped, nb_o = plan.phase_times()
-    # exclusive per-phase times and clocks: one more batch with both sectors on one stream (outside the timed region)
-    solo = _lib.CircuitPlan(comp, c["Lx"], c["Lz"], gr[0], gr[1], pr[0], pr[1], mk[0], mk[1], p, max_iter=args.max_iter, use_osd=True,
-                            flags=flags | _lib.FLAG_MC_UNFUSED, batch=B)
-    solo.run(SEED + 1, trial0(0), B, stream)
-    solo.read(stream, clear=True)
-    solo.phase_times()
-    phases, nb = None, 1
-    for _ in range(3):                                   # the same batch three times; a phase's time is its fastest run (a single batch is noisy)
-        solo.read(stream, clear=True)
-        solo.run(SEED, trial0(0), B, stream)
-        solo_tally = solo.read(stream)
-        ph, _nb = solo.phase_times()
-        phases = ph if phases is None else {k: min(phases[k], ph[k]) for k in ph}
-    clk_bp, clk_osd = solo.clock(stream)
-    solo.close()
+    phases, nb = plan.phase_times()        # both sectors run on the caller's stream: the hipEvent spans are exclusive and sum to the step
+    solo_tally = tally
+    clk_bp, clk_osd = plan.clock(stream)
     trials = world * K * B
     if int(total[T["trials"]]) != trials:
         raise SystemExit(f"circuit tally counts {int(total[T['trials']])} trials, expected {trials}")
@@ -532,9 +519,7 @@ def circuit_leg(args, _lib, rank, world, local_rank, stream, barrier, reduce_tal
                                f"logical comparison (reference early-exit semantics), batch={B} trials/step/GPU",
                    "matrices": args.circuit, "batch": B, "seed": SEED, "flags": args.circuit_flags},
         "phases_ms_per_step": {k: round(v / max(nb, 1), 3) for k, v in phases.items()},
-        "phases_note": "hipEvent spans of an extra batch run with both sectors on ONE stream (exclusive times, fastest of three runs of the same batch; they sum to the serial step). The timed steps run "
-                       "sector X on the plan's second stream beside sector Z (spans then overlap): phases_ms_per_step_overlapped",
-        "phases_ms_per_step_overlapped": {k: round(v / max(nb_o, 1), 3) for k, v in phases_overlapped.items()},
+        "phases_note": "hipEvent spans of the timed steps, mean per step (one stream: exclusive times that sum to the step)",
         "logical_error_rate": round(float(total[T["total_err"]]) / trials, 4),
         "bp_converged": {"z": round(float(total[T["bp_conv_z"]]) / trials, 4), "x": round(float(total[T["bp_conv_x"]]) / trials, 4)},
         "mean_iterations": round(float(mean_it), 2),

@@ -20,7 +20,7 @@ def select_build(name):
     global SO_PATH, BUILD
     if _lib is not None and name != BUILD:
         raise QldpcError(f"library already loaded ({BUILD}); select_build must come first")
-    fn = {"product": "libqldpc_hip.so", "experiments": "libqldpc_hip_experiments.so", "timers": "libqldpc_hip_timers.so"}[name]
+    fn = {"product": "libqldpc_hip.so", "experiments": "libqldpc_hip_experiments.so", "timers": "libqldpc_hip_timers.so"}.get(name, name)   # or a file name in csrc/ (A/B builds of tools/)
     SO_PATH, BUILD = os.path.join(_HERE, "csrc", fn), name
 
 ALPHA_CONST, ALPHA_DYNAMIC, ALPHA_SEQ = 0, 1, 2

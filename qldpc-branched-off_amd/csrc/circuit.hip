@@ -69,8 +69,10 @@ __device__ __forceinline__ void xor_signature(const SigTab &T, int e, uint32_t *
 __global__ __launch_bounds__(256) void circuit_sample_kernel(int64_t B, int64_t trial_begin, uint32_t seed_lo, uint32_t seed_hi, uint32_t thr,
                                                              int n_locs, const uint8_t *__restrict__ loc_type, SigTab Z, SigTab X, int nsx,
                                                              int nsz, int8_t *__restrict__ syn_z, int8_t *__restrict__ syn_x,
-                                                             unsigned long long *__restrict__ true_z, unsigned long long *__restrict__ true_x) {
+                                                             unsigned long long *__restrict__ true_z, unsigned long long *__restrict__ true_x,
+                                                             int32_t *__restrict__ fail_counts) {
     extern __shared__ uint32_t sm[];
+    if (fail_counts && blockIdx.x == 0 && threadIdx.x < 8) fail_counts[threadIdx.x] = 0;      // [0] Z, [4] X BP failures of this batch (no memset launches)
     const int wz = (nsx + 31) >> 5, wx = (nsz + 31) >> 5;
     uint32_t *bz = sm, *bx = sm + wz;
     unsigned long long *lacc = reinterpret_cast<unsigned long long *>(sm + ((wz + wx + 1) & ~1));
@@ -141,9 +143,14 @@ __device__ __forceinline__ void judge_sector(const JudgeSector &S, int64_t b, in
 }
 
 __global__ __launch_bounds__(256) void circuit_judge_kernel(int64_t B, JudgeSector Z, JudgeSector X, unsigned long long *__restrict__ tally,
-                                                            uint8_t *__restrict__ outcome) {
+                                                            uint8_t *__restrict__ outcome, const int32_t *__restrict__ fail_counts) {
     __shared__ unsigned long long acc[QLDPC_TALLY_SLOTS];
     if (threadIdx.x < QLDPC_TALLY_SLOTS) acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    if (fail_counts && blockIdx.x == 0 && threadIdx.x == 0) {                 // OSD-0 calls of this batch = its BP failures per sector
+        acc[QLDPC_TALLY_OSD_Z] = (unsigned long long)fail_counts[0];
+        acc[QLDPC_TALLY_OSD_X] = (unsigned long long)fail_counts[4];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 31;
     const int64_t b = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -174,9 +181,6 @@ __global__ __launch_bounds__(256) void circuit_judge_kernel(int64_t B, JudgeSect
 __global__ void collect_failed2_kernel(int64_t B, const uint8_t *__restrict__ conv, int32_t *__restrict__ list, int32_t *__restrict__ count) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B && !conv[b]) list[atomicAdd(count, 1)] = (int32_t)b;
-}
-__global__ void add_count_kernel(const int32_t *count, unsigned long long *slot) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(slot, (unsigned long long)*count);
 }
 
 }  // namespace qldpc
@@ -431,19 +435,14 @@ QLDPC_EXPORT int qldpc_circuit_plan_create(const qldpc_circuit_desc *D, const ql
         (rc = P->d_tally.ensure(QLDPC_TALLY_SLOTS * 8)) || (rc = P->d_clk.ensure(2 * kClkSlots * 16)))
         return fail(rc);
     if (hipMemset(P->d_clk.p, 0, 2 * kClkSlots * 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
-    if (!(flags & QLDPC_FLAG_MC_UNFUSED)) {
-        if (hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&P->ev_sampled, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&P->ev_x_done, hipEventDisableTiming) != hipSuccess) {
-            set_error("stream / event creation failed: %s", hipGetErrorString(hipGetLastError()));
-            return fail(QLDPC_ERR_HIP);
-        }
-    }
+    // (round 2 ran sector X on a second stream beside sector Z: two persistent kernels that each own every CU do not overlap -- 177.9 vs 178.7 ms
+    // per step -- and the small launches queued behind them polluted the profile; everything runs on the caller's stream now)
     if (hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
     *out = P;
     return QLDPC_OK;
 }
 
-static int launch_sampler(qldpc_circuit_plan *P, uint64_t seed, int64_t begin, int64_t B, hipStream_t s) {
+static int launch_sampler(qldpc_circuit_plan *P, uint64_t seed, int64_t begin, int64_t B, hipStream_t s, bool zero_counts = false) {
     SigTab Z{P->d_zptr.as<int32_t>(), P->d_zidx.as<uint16_t>(), P->d_zlog.as<uint64_t>()};
     SigTab X{P->d_xptr.as<int32_t>(), P->d_xidx.as<uint16_t>(), P->d_xlog.as<uint64_t>()};
     const int wz = (P->nsx + 31) / 32, wx = (P->nsz + 31) / 32;
@@ -451,7 +450,7 @@ static int launch_sampler(qldpc_circuit_plan *P, uint64_t seed, int64_t begin, i
     const unsigned grid = (unsigned)std::min<int64_t>(B, 256 * 16);
     hipLaunchKernelGGL(circuit_sample_kernel, dim3(grid), dim3(256), lds, s, B, begin, (uint32_t)seed, (uint32_t)(seed >> 32), P->thr, P->n_locs,
                        P->d_loc_type.as<uint8_t>(), Z, X, P->nsx, P->nsz, P->d_syn_z.as<int8_t>(), P->d_syn_x.as<int8_t>(),
-                       P->d_true_z.as<unsigned long long>(), P->d_true_x.as<unsigned long long>());
+                       P->d_true_z.as<unsigned long long>(), P->d_true_x.as<unsigned long long>(), zero_counts ? P->d_count.as<int32_t>() : (int32_t *)nullptr);
     QLDPC_HIP_TRY(hipGetLastError());
     return QLDPC_OK;
 }
@@ -474,7 +473,6 @@ static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B,
     if (rc != QLDPC_OK) return rc;
     if ((rc = phase_mark(P, ph_bp, s, false)) != QLDPC_OK || !P->use_osd) return rc;
     if ((rc = phase_mark(P, ph_osd, s, true)) != QLDPC_OK) return rc;
-    QLDPC_HIP_TRY(hipMemsetAsync(count, 0, 4, s));
     hipLaunchKernelGGL(collect_failed2_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, conv.as<uint8_t>(), list.as<int32_t>(), count);
     {
         std::lock_guard<std::mutex> lk(g->mu);
@@ -484,9 +482,8 @@ static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B,
         g->clk_probe = nullptr;
     }
     if (rc != QLDPC_OK) return rc;
-    hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(64), 0, s, count, P->d_tally.as<unsigned long long>() + (sector ? QLDPC_TALLY_OSD_X : QLDPC_TALLY_OSD_Z));
     QLDPC_HIP_TRY(hipGetLastError());
-    return phase_mark(P, ph_osd, s, false);
+    return phase_mark(P, ph_osd, s, false);                      // (the judge kernel adds the two failure counts to the OSD tally slots)
 }
 
 // one pass over [trial_begin, trial_begin + count); `outcome` (host, may be NULL) receives bit0 = z_err, bit1 = x_err per trial
@@ -498,7 +495,7 @@ static int circuit_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin
         const int64_t B = std::min<int64_t>(P->batch, count - off);
         if (P->pending.size() > 256) drain_phases(P, false);         // a caller that never reads phase times: recycle finished brackets (bounded event count)
         if ((rc = phase_mark(P, QLDPC_PHASE_SAMPLE, s, true)) != QLDPC_OK) return rc;
-        if ((rc = launch_sampler(P, seed, trial_begin + off, B, s)) != QLDPC_OK) return rc;
+        if ((rc = launch_sampler(P, seed, trial_begin + off, B, s, true)) != QLDPC_OK) return rc;
         if ((rc = phase_mark(P, QLDPC_PHASE_SAMPLE, s, false)) != QLDPC_OK) return rc;
         hipStream_t sx = s;
         if (P->side && P->gz != P->gx) {                // sector X on the plan's own stream, joined again before the judge
@@ -518,7 +515,7 @@ static int circuit_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin
         JudgeSector X{P->gx->m, P->gx->n, P->gx->d_indptr, P->gx->d_indices, P->d_lm_x.as<uint64_t>(), P->d_syn_x.as<int8_t>(), P->d_det_x.as<int8_t>(),
                       P->d_conv_x.as<uint8_t>(), P->d_iter_x.as<int32_t>(), P->d_true_x.as<unsigned long long>()};
         hipLaunchKernelGGL(circuit_judge_kernel, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, B, Z, X, P->d_tally.as<unsigned long long>(),
-                           outcome ? P->d_outcome.as<uint8_t>() : (uint8_t *)nullptr);
+                           outcome ? P->d_outcome.as<uint8_t>() : (uint8_t *)nullptr, P->use_osd ? P->d_count.as<int32_t>() : (const int32_t *)nullptr);
         QLDPC_HIP_TRY(hipGetLastError());
         if ((rc = phase_mark(P, QLDPC_PHASE_JUDGE, s, false)) != QLDPC_OK) return rc;
         P->batches++;           // (the next batch's sampler follows the judge on s, which already waited for sector X)

@@ -114,6 +114,9 @@ int gf2_spmv_launch(const qldpc_graph *g, int64_t B, const int8_t *d_vec, int8_t
 using namespace qldpc;
 
 // ------------------------------------------------------------------------------------------ plan
+static const int64_t kFanBatch = 32768;
+static const int kFanLanes = 8;
+
 struct qldpc_cc_plan {
     const qldpc_graph *g = nullptr;
     int k = 0, max_iter = 0, use_osd = 0, flags = 0;
@@ -123,12 +126,20 @@ struct qldpc_cc_plan {
     std::vector<double> alpha;
     DevBuf d_alpha, d_prior, d_Lmask, d_err, d_synd, d_dec, d_llr, d_conv, d_iter, d_tally, d_list, d_count, d_sol, d_cold, d_clk;
     DevBuf d_lptr, d_lidx, d_cont;        // logical rows in CSR form and the list of shots the bit-sliced first iteration hands on (mc_first.hip)
-    // Fused pipeline: the tail of a batch (OSD-0 on its BP failures + their judge: a latency-bound ~0.1 ms on a handful of CUs) runs on the plan's
-    // side stream beside the NEXT batch's decode.  Failure records are double-buffered: set i = batch parity; set 0 is the buffers above.
-    DevBuf d_err2, d_synd2, d_dec2, d_llr2, d_list2, d_count2, d_cold2;
+    // Fused pipeline, failure records per LANE (lane 0 = the buffers above).  Two ways of keeping the chip busy between batches:
+    //   large batches (2 lanes, reference semantics only): the tail of batch k (OSD-0 on its BP failures + their judge: a latency-bound ~0.1 ms on a
+    //     handful of CUs) runs on the plan's side stream beside the decode of batch k + 1 on the caller's stream; the lanes double-buffer the records;
+    //   small batches (batch <= kFanBatch, kFanLanes lanes): one launch of a few thousand shots cannot fill 256 CUs (BASELINE config 2 is quoted at
+    //     batch 4096: 585 workgroups), so batch k runs ENTIRELY on lane k % kFanLanes' own stream and up to kFanLanes batches are in flight at once.
+    //     The lanes start behind whatever the caller had enqueued on its stream; qldpc_cc_plan_read joins them.
+    // (a fan-out lane owns a private copy of the graph handle: the OSD-0 workspaces hang off the handle and are handed over between streams in
+    // order, which would serialise the tails of concurrent batches)
+    struct Lane { DevBuf err, synd, dec, llr, list, count, cold, cont; hipStream_t st = nullptr; hipEvent_t decoded = nullptr, tail = nullptr; bool tail_pending = false;
+                  qldpc_graph *g = nullptr; };
+    std::vector<Lane> lanes;              // lane 0 uses d_err, d_synd, ... above
     hipStream_t side = nullptr;
-    hipEvent_t ev_decoded[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
-    bool tail_pending[2] = {false, false};
+    hipEvent_t ev_in = nullptr;
+    bool fan = false;
     int64_t batch_no = 0;
     bool clk_first = false;               // the last launch stamped the first-iteration kernel's probe buffer
     bool first_ok = false;                // the closed form of iteration 0 applies to this plan (uniform prior > 0, column degree <= 3, ...)
@@ -223,17 +234,32 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
                                        P->d_synd.as<int8_t>(), P->d_err.as<int8_t>(), P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
                                        (flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() : nullptr)) != QLDPC_OK)
             return fail(rc);
-        if (mc_tail_overlap_choice() == 1 && use_osd) {
-            if ((rc = P->d_err2.ensure(batch * n)) || (rc = P->d_synd2.ensure(batch * m)) || (rc = P->d_dec2.ensure(batch * n)) || (rc = P->d_llr2.ensure(batch * n * 8)) ||
-                (rc = P->d_list2.ensure(batch * 4)) || (rc = P->d_count2.ensure(16)) || (rc = P->d_cold2.ensure(mc_regular_cold_bytes())))
-                return fail(rc);
-            if ((rc = mc_regular_fill_cold(P->d_cold2.p, P->d_tally.as<unsigned long long>(), P->d_count2.as<int32_t>(), P->d_list2.as<int32_t>(),
-                                           P->d_synd2.as<int8_t>(), P->d_err2.as<int8_t>(), P->d_dec2.as<int8_t>(), P->d_llr2.as<double>(),
-                                           (flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() : nullptr)) != QLDPC_OK)
-                return fail(rc);
-            bool ok = hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) == hipSuccess;
-            for (int i = 0; i < 2 && ok; i++)
-                ok = hipEventCreateWithFlags(&P->ev_decoded[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&P->ev_tail[i], hipEventDisableTiming) == hipSuccess;
+        // (fixed-work plans with large batches keep everything on the caller's stream: beside a 13 ms decode launch the 0.1 ms tail gains nothing, and
+        // measured concurrently it slows the persistent decode kernel by 5 %, profiles/r03_experiments.txt)
+        if (mc_tail_overlap_choice() == 1 && (!(flags & QLDPC_FLAG_FIXED_ITERS) || batch <= kFanBatch)) {
+            P->fan = batch <= kFanBatch;
+            const int nl = P->fan ? kFanLanes : (use_osd ? 2 : 1);
+            P->lanes.resize(nl);
+            bool ok = true;
+            for (int i = 1; i < nl; i++) {              // lane 0 = the plan's own buffers
+                qldpc_cc_plan::Lane &Ln = P->lanes[i];
+                if ((rc = Ln.err.ensure(batch * n)) || (rc = Ln.synd.ensure(batch * m)) || (rc = Ln.dec.ensure(batch * n)) || (rc = Ln.llr.ensure(batch * n * 8)) ||
+                    (rc = Ln.list.ensure(batch * 4)) || (rc = Ln.count.ensure(16)) || (rc = Ln.cold.ensure(mc_regular_cold_bytes())) ||
+                    (P->first_ok && (rc = Ln.cont.ensure(batch * 4))))
+                    return fail(rc);
+                if ((rc = mc_regular_fill_cold(Ln.cold.p, P->d_tally.as<unsigned long long>(), Ln.count.as<int32_t>(), Ln.list.as<int32_t>(), Ln.synd.as<int8_t>(),
+                                               Ln.err.as<int8_t>(), Ln.dec.as<int8_t>(), Ln.llr.as<double>(),
+                                               (flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() : nullptr)) != QLDPC_OK)
+                    return fail(rc);
+            }
+            for (int i = 0; i < nl && ok; i++) {
+                qldpc_cc_plan::Lane &Ln = P->lanes[i];
+                ok = hipEventCreateWithFlags(&Ln.decoded, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&Ln.tail, hipEventDisableTiming) == hipSuccess;
+                if (ok && P->fan) ok = hipStreamCreateWithFlags(&Ln.st, hipStreamNonBlocking) == hipSuccess;
+                if (ok && P->fan && i > 0 && use_osd && qldpc_graph_create(g->m, g->n, g->indptr.data(), g->indices.data(), g->device, &Ln.g) != QLDPC_OK) return fail(QLDPC_ERR_HIP);
+            }
+            if (ok && !P->fan && nl == 2) ok = hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) == hipSuccess;
+            if (ok && P->fan) ok = hipEventCreateWithFlags(&P->ev_in, hipEventDisableTiming) == hipSuccess;
             if (!ok) { set_error("stream / event creation failed: %s", hipGetErrorString(hipGetLastError())); return fail(QLDPC_ERR_HIP); }
         }
     }
@@ -249,17 +275,26 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const qldpc_graph *g = P->g;
     const int n = g->n, m = g->m;
+    bool joined_lanes[kFanLanes] = {false};
+    if (P->fused && P->fan && count > 0) QLDPC_HIP_TRY(hipEventRecord(P->ev_in, s));      // the lanes start behind the caller's earlier work
     for (int64_t off = 0; off < count; off += P->batch) {
         const int64_t B = (count - off < P->batch) ? (count - off) : P->batch;
         if (P->fused) {
             // one launch: sample -> syndrome -> decode -> logical compare -> tally; BP failures are exported for OSD-0.
             // The failure records reuse the per-shot buffers of the unfused path (synd/err/dec/llr), compacted.
-            // failure-record set of this batch; its previous user (the tail of batch k - 2 on the side stream) must be done
-            const int set = P->side ? (int)(P->batch_no & 1) : 0;
+            // the lane of this batch: its failure-record buffers and, for small batches, its own stream
+            const int nl = (int)P->lanes.size();
+            const int set = nl > 1 ? (int)(P->batch_no % nl) : 0;
             P->batch_no++;
-            DevBuf &b_count = set ? P->d_count2 : P->d_count, &b_list = set ? P->d_list2 : P->d_list, &b_synd = set ? P->d_synd2 : P->d_synd,
-                   &b_err = set ? P->d_err2 : P->d_err, &b_dec = set ? P->d_dec2 : P->d_dec, &b_llr = set ? P->d_llr2 : P->d_llr, &b_cold = set ? P->d_cold2 : P->d_cold;
-            if (P->side && P->tail_pending[set]) QLDPC_HIP_TRY(hipStreamWaitEvent(s, P->ev_tail[set], 0));
+            qldpc_cc_plan::Lane *Ln = nl ? &P->lanes[set] : nullptr;
+            DevBuf &b_count = set ? Ln->count : P->d_count, &b_list = set ? Ln->list : P->d_list, &b_synd = set ? Ln->synd : P->d_synd, &b_err = set ? Ln->err : P->d_err,
+                   &b_dec = set ? Ln->dec : P->d_dec, &b_llr = set ? Ln->llr : P->d_llr, &b_cold = set ? Ln->cold : P->d_cold, &b_cont = set ? Ln->cont : P->d_cont;
+            hipStream_t caller = s;
+            if (P->fan) {                                        // everything of this batch on the lane's stream, behind the caller's earlier work
+                if (!joined_lanes[set]) { QLDPC_HIP_TRY(hipStreamWaitEvent(Ln->st, P->ev_in, 0)); joined_lanes[set] = true; }
+                s = Ln->st;
+            }
+            if (P->side && Ln->tail_pending) QLDPC_HIP_TRY(hipStreamWaitEvent(s, Ln->tail, 0));
             QLDPC_HIP_TRY(hipMemsetAsync(b_count.p, 0, 16, s));          // [0] BP failures (OSD-0 list), [2] shots handed on by the first iteration
             hipEvent_t e0 = get_event(P), e1 = get_event(P);
             if (e0 && e1) QLDPC_HIP_TRY(hipEventRecord(e0, s));
@@ -268,11 +303,11 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
                 unsigned long long *clk = (P->flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() + 2 * kClkSlots : nullptr;
                 P->clk_first = true;
                 if ((rc = mc_first_launch(g, P->k, P->d_lptr.as<int32_t>(), P->d_lidx.as<int32_t>(), B, seed, shot_begin + off, P->thr, P->negbits,
-                                          P->d_tally.as<unsigned long long>(), P->d_cont.as<int32_t>(), b_count.as<int32_t>() + 2, clk, s)) != QLDPC_OK)
+                                          P->d_tally.as<unsigned long long>(), b_cont.as<int32_t>(), b_count.as<int32_t>() + 2, clk, s)) != QLDPC_OK)
                     return rc;
                 if (e0) { hipEvent_t em = get_event(P); if (em) { QLDPC_HIP_TRY(hipEventRecord(em, s)); P->pending_first.emplace_back(e0, em); } }
                 rc = mc_regular_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags & ~QLDPC_FLAG_CLOCK_PROBE, P->nanfree, seed,
-                                       shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), b_cold.p, s, P->d_cont.as<int32_t>(),
+                                       shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), b_cold.p, s, b_cont.as<int32_t>(),
                                        b_count.as<int32_t>() + 2);
             }
 #ifdef QLDPC_EXPERIMENTS
@@ -289,18 +324,20 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
                 hipStream_t ts = s;
                 if (P->side) {                                           // the tail follows the decode on the side stream
                     ts = P->side;
-                    QLDPC_HIP_TRY(hipEventRecord(P->ev_decoded[set], s));
-                    QLDPC_HIP_TRY(hipStreamWaitEvent(ts, P->ev_decoded[set], 0));
+                    QLDPC_HIP_TRY(hipEventRecord(Ln->decoded, s));
+                    QLDPC_HIP_TRY(hipStreamWaitEvent(ts, Ln->decoded, 0));
                 }
-                std::lock_guard<std::mutex> lk(g->mu);
-                if ((rc = osd0_listed_launch(g, b_list.as<int32_t>(), b_count.as<int32_t>(), b_synd.as<int8_t>(), b_llr.as<double>(),
+                const qldpc_graph *go = (Ln && Ln->g) ? Ln->g : g;
+                std::lock_guard<std::mutex> lk(go->mu);
+                if ((rc = osd0_listed_launch(go, b_list.as<int32_t>(), b_count.as<int32_t>(), b_synd.as<int8_t>(), b_llr.as<double>(),
                                              b_dec.as<int8_t>(), nullptr, b_dec.as<int8_t>(), P->flags, ts)) != QLDPC_OK)
                     return rc;
                 if ((rc = judge_failed_launch(g, b_count.as<int32_t>(), P->d_Lmask.as<uint64_t>(), b_err.as<int8_t>(), b_synd.as<int8_t>(),
                                               b_dec.as<int8_t>(), P->d_tally.as<unsigned long long>(), ts)) != QLDPC_OK)
                     return rc;
-                if (P->side) { QLDPC_HIP_TRY(hipEventRecord(P->ev_tail[set], ts)); P->tail_pending[set] = true; }
+                if (P->side) { QLDPC_HIP_TRY(hipEventRecord(Ln->tail, ts)); Ln->tail_pending = true; }
             }
+            s = caller;
             continue;
         }
         const int64_t nq = (n + 3) / 4;
@@ -367,7 +404,8 @@ QLDPC_EXPORT int qldpc_cc_plan_read(qldpc_cc_plan *P, void *stream, int clear, i
     int rc = QLDPC_OK; (void)rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     QLDPC_HIP_TRY(hipStreamSynchronize(s));
-    if (P->side) { QLDPC_HIP_TRY(hipStreamSynchronize(P->side)); P->tail_pending[0] = P->tail_pending[1] = false; }
+    if (P->side) QLDPC_HIP_TRY(hipStreamSynchronize(P->side));
+    for (auto &Ln : P->lanes) { if (Ln.st) QLDPC_HIP_TRY(hipStreamSynchronize(Ln.st)); Ln.tail_pending = false; }
     QLDPC_HIP_TRY(hipMemcpy(tally, P->d_tally.p, QLDPC_TALLY_SLOTS * 8, hipMemcpyDeviceToHost));
     if (clear) QLDPC_HIP_TRY(hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8));
     return QLDPC_OK;
@@ -398,6 +436,7 @@ QLDPC_EXPORT int qldpc_cc_plan_clock(qldpc_cc_plan *P, void *stream, double *mhz
     QLDPC_REQUIRE((P->flags & QLDPC_FLAG_CLOCK_PROBE) && P->fused, "the plan was created without QLDPC_FLAG_CLOCK_PROBE (or does not use the fused kernel)");
     QLDPC_USE_DEVICE(P->g->device);
     QLDPC_HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    for (auto &Ln : P->lanes) if (Ln.st) QLDPC_HIP_TRY(hipStreamSynchronize(Ln.st));
     std::vector<unsigned long long> h(2 * kClkSlots);
     QLDPC_HIP_TRY(hipMemcpy(h.data(), P->d_clk.as<unsigned long long>() + (P->clk_first ? 2 * kClkSlots : 0), h.size() * 8, hipMemcpyDeviceToHost));
     *mhz = clock_probe_median(h.data(), kClkSlots);
@@ -411,10 +450,16 @@ QLDPC_EXPORT void qldpc_cc_plan_destroy(qldpc_cc_plan *P) {
     for (auto &pr : P->pending_first) (void)hipEventDestroy(pr.second);
     for (auto e : P->pool) (void)hipEventDestroy(e);
     if (P->side) { (void)hipStreamSynchronize(P->side); (void)hipStreamDestroy(P->side); }
-    for (int i = 0; i < 2; i++) { if (P->ev_decoded[i]) (void)hipEventDestroy(P->ev_decoded[i]); if (P->ev_tail[i]) (void)hipEventDestroy(P->ev_tail[i]); }
+    if (P->ev_in) (void)hipEventDestroy(P->ev_in);
+    for (auto &Ln : P->lanes) {
+        if (Ln.st) { (void)hipStreamSynchronize(Ln.st); (void)hipStreamDestroy(Ln.st); }
+        if (Ln.decoded) (void)hipEventDestroy(Ln.decoded);
+        if (Ln.tail) (void)hipEventDestroy(Ln.tail);
+        if (Ln.g) qldpc_graph_destroy(Ln.g);
+        for (DevBuf *b : {&Ln.err, &Ln.synd, &Ln.dec, &Ln.llr, &Ln.list, &Ln.count, &Ln.cold, &Ln.cont}) b->release();
+    }
     for (DevBuf *b : {&P->d_alpha, &P->d_prior, &P->d_Lmask, &P->d_err, &P->d_synd, &P->d_dec, &P->d_llr, &P->d_conv, &P->d_iter,
-                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol, &P->d_cold, &P->d_clk, &P->d_lptr, &P->d_lidx, &P->d_cont,
-                      &P->d_err2, &P->d_synd2, &P->d_dec2, &P->d_llr2, &P->d_list2, &P->d_count2, &P->d_cold2})
+                      &P->d_tally, &P->d_list, &P->d_count, &P->d_sol, &P->d_cold, &P->d_clk, &P->d_lptr, &P->d_lidx, &P->d_cont})
         b->release();
     delete P;
 }

@@ -27,6 +27,30 @@ __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1,
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// NB independent Philox4x32-10 blocks with the ROUND loop outermost: the ten rounds of one block are a dependent chain of 64-bit multiplies
+// (ILP 2); written one block after the other the compiler leaves them that way and a wave that holds several blocks waits for every multiply
+// (mc_first.hip: 2.6x off its issue time).  Same outputs as philox4x32_10 per block: block i uses counter (c0[i], c1[i], c2, c3).
+template <int NB>
+__device__ __forceinline__ void philox4x32_10_batch(const uint32_t (&c0)[NB], const uint32_t (&c1)[NB], uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                                    uint32_t (&out)[NB][4]) {
+    uint32_t a[NB], b[NB], c[NB], d[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) { a[i] = c0[i]; b[i] = c1[i]; c[i] = c2; d[i] = c3; }
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * a[i], p1 = (uint64_t)0xCD9E8D57u * c[i];
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ b[i] ^ k0, n1 = (uint32_t)p1;
+            const uint32_t n2 = (uint32_t)(p0 >> 32) ^ d[i] ^ k1, n3 = (uint32_t)p0;
+            a[i] = n0; b[i] = n1; c[i] = n2; d[i] = n3;
+        }
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) { out[i][0] = a[i]; out[i][1] = b[i]; out[i][2] = c[i]; out[i][3] = d[i]; }
+}
+
 inline uint32_t bernoulli_threshold(double p) {
     if (p <= 0.0) return 0u;
     if (p >= 1.0) return 0xFFFFFFFFu;

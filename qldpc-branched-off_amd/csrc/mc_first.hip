@@ -48,8 +48,9 @@ __global__ __launch_bounds__(64, 2) void mc_first_kernel(FirstArgs A) {
     extern __shared__ unsigned char lds[];
     typedef typename std::conditional<BITS <= 8, uint8_t, typename std::conditional<BITS <= 16, uint16_t, uint32_t>::type>::type word_t;
     const int lane = threadIdx.x, m = A.m, n = A.n;
-    word_t *E = reinterpret_cast<word_t *>(lds);                    // [n][64]: error plane j, later d = e xor hard_0
-    word_t *S = E + (size_t)n * 64;                                 // [m][64]: syndrome plane i
+    // (restrict: the two plane arrays do not overlap, so the reads of one row's columns need not wait for the previous row's store)
+    word_t *__restrict__ E = reinterpret_cast<word_t *>(lds);       // [n][64]: error plane j, later d = e xor hard_0
+    word_t *__restrict__ S = reinterpret_cast<word_t *>(lds) + (size_t)n * 64;     // [m][64]: syndrome plane i
     const unsigned full = (BITS == 32) ? 0xFFFFFFFFu : ((1u << BITS) - 1u);
     const int64_t per_wave = (int64_t)64 * BITS;
     const ClkStamp clk0 = clk_begin(A.clk);
@@ -63,12 +64,15 @@ __global__ __launch_bounds__(64, 2) void mc_first_kernel(FirstArgs A) {
         for (int q = 0; q < nq; q++) {
             unsigned acc[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int sh = 0; sh < BITS; sh++) {
-                const uint64_t g = (uint64_t)(A.shot_begin + first + sh);
-                uint32_t o[4];
-                philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)q, 0u, A.seed_lo, A.seed_hi, o);
+            for (int sh0 = 0; sh0 < BITS; sh0 += 8) {                 // eight shots' blocks at a time, their rounds interleaved (mc_common.h)
+                uint32_t glo[8], ghi[8], o[8][4];
 #pragma unroll
-                for (int w = 0; w < 4; w++) acc[w] |= (o[w] < A.thr ? 1u : 0u) << sh;
+                for (int i = 0; i < 8; i++) { const uint64_t g = (uint64_t)(A.shot_begin + first + sh0 + i); glo[i] = (uint32_t)g; ghi[i] = (uint32_t)(g >> 32); }
+                philox4x32_10_batch<8>(glo, ghi, (uint32_t)q, 0u, A.seed_lo, A.seed_hi, o);
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) acc[w] |= (o[i][w] < A.thr ? 1u : 0u) << (sh0 + i);
             }
 #pragma unroll
             for (int w = 0; w < 4; w++)
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(64, 2) void mc_first_kernel(FirstArgs A) {
         }
         // ---- s = H e (a6, kernels.py:222-231) ----
         unsigned anys = 0u;
-#pragma unroll 2
+#pragma unroll 4
         for (int i = 0; i < m; i++) {
             unsigned s = 0u;
             if (CDEG > 0) {
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(64, 2) void mc_first_kernel(FirstArgs A) {
             anys |= s;
         }
         // ---- hard_0 from the number of unsatisfied neighbour checks (bit-sliced 2-bit counter), d = e xor hard_0 in place ----
-#pragma unroll 2
+#pragma unroll 4
         for (int j = 0; j < n; j++) {
             const int c0 = (VDEG > 0) ? j * VDEG : A.colptr[j], deg = (VDEG > 0) ? VDEG : A.colptr[j + 1] - c0;          // deg <= 3 (host-checked)
             unsigned u0 = 0u, u1 = 0u;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(64, 2) void mc_first_kernel(FirstArgs A) {
         }
         // ---- stop test: H hard_0 == s  <=>  H d == 0 (kernels.py:352-364) ----
         unsigned unsat = 0u;
-#pragma unroll 2
+#pragma unroll 4
         for (int i = 0; i < m; i++) {
             unsigned s = 0u;
             if (CDEG > 0) {

@@ -42,6 +42,10 @@ struct RegArgs {
     int offV, offE, offL, offI, offA, offT;
 };
 
+#ifndef QLDPC_REG_SIGNBITS
+#define QLDPC_REG_SIGNBITS 0      // 1: clean inputs take signs, parities and the message sign from the high words (integer XORs) instead of f64 compares --
+                                  // 12 fewer 4-cycle compares per check, measured 1.1 % SLOWER (12.74 / 12.78 vs 12.60 / 12.63 ms, same box, profiles/r03_experiments.txt)
+#endif
 #ifndef QLDPC_LB_T
 #define QLDPC_LB_T 512
 #define QLDPC_LB_W 8
@@ -152,8 +156,15 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
             double x[CDEG];
             if (in_check) {
                 bool par = csyn;
+                if (NANFREE && QLDPC_REG_SIGNBITS) {                  // clean inputs: a posterior is never -0.0 (minsum_common.h), so x < 0 <=> its sign bit: one XOR per edge
+                    unsigned ph = 0u;
 #pragma unroll
-                for (int k = 0; k < CDEG; k++) { x[k] = Vl[coff[k]]; par ^= (x[k] < 0.0); }   // kernels.py:349,356
+                    for (int k = 0; k < CDEG; k++) { x[k] = Vl[coff[k]]; ph ^= (unsigned)__double2hiint(x[k]); }
+                    par ^= (ph >> 31) != 0u;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CDEG; k++) { x[k] = Vl[coff[k]]; par ^= (x[k] < 0.0); }   // kernels.py:349,356
+                }
                 if (it >= 1 && !done && par) unsat[it & 1] = 1;                               // kernels.py:357-359
             }
             // Reference semantics, iteration 1: at BASELINE's error rates ~97 % of the shots pass the syndrome test of values_0 here, and the
@@ -198,11 +209,15 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
                     }
                     bool neg[CDEG];
                     bool sp = csyn;                                                            // sign of 1 - 2 s (kernels.py:252,289)
+                    unsigned spw = csyn ? 0x80000000u : 0u;                                    // the same in the sign bit of a word (NANFREE: Q is never -0.0)
 #pragma unroll
                     for (int k = 0; k < CDEG; k++) {
                         if (DAMP) Qold[k] = x[k];
-                        neg[k] = NANFREE ? (x[k] < 0.0) : !(x[k] >= 0.0);                      // kernels.py:296-299 (-0.0 counts as >= 0)
-                        sp ^= neg[k];
+                        if (NANFREE && !DAMP && QLDPC_REG_SIGNBITS) { spw ^= (unsigned)__double2hiint(x[k]); neg[k] = false; }
+                        else {
+                            neg[k] = NANFREE ? (x[k] < 0.0) : !(x[k] >= 0.0);                  // kernels.py:296-299 (-0.0 counts as >= 0)
+                            sp ^= neg[k];
+                        }
                     }
                     double min1, min2;
                     if (NANFREE) {
@@ -223,7 +238,8 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
                     for (int k = 0; k < CDEG; k++) {
                         const bool eq = (fabs(x[k]) == min1);
                         const int lo = eq ? p2lo : p1lo;
-                        const int hi = (eq ? p2hi : p1hi) ^ ((sp != neg[k]) ? (int)0x80000000 : 0);   // kernels.py:311-314
+                        const int hi = (NANFREE && !DAMP && QLDPC_REG_SIGNBITS) ? (int)(((unsigned)(eq ? p2hi : p1hi)) ^ ((spw ^ (unsigned)__double2hiint(x[k])) & 0x80000000u))
+                                                          : ((eq ? p2hi : p1hi) ^ ((sp != neg[k]) ? (int)0x80000000 : 0));   // kernels.py:311-314
                         const double msg = __hiloint2double(hi, lo);
                         Rprev[k] = msg;
                         Rl[roff + k] = msg;
@@ -363,7 +379,10 @@ __global__ __launch_bounds__(256) void cc_judge_failed_kernel(const int32_t *__r
 struct RegPlan { int cdeg, vdeg, TS, S, offV, offE, offL, offI, offA, offT; size_t lds; unsigned block; };
 static const int kMaxIterLds = 1024;
 
-static bool plan_regular(const qldpc_graph *g, int max_iter, RegPlan &P) {
+static int g_list_shots = 0;          // qldpc_set_option("mc_list_shots"): shots per workgroup of the shot-list launch (0 = as the full launch)
+void regular_set_list_shots(int s) { g_list_shots = s; }
+
+static bool plan_regular(const qldpc_graph *g, int max_iter, RegPlan &P, int force_S = 0) {
     if (g->m <= 0 || g->n <= 0 || max_iter > kMaxIterLds) return false;
     const int cdeg = g->max_row_deg, vdeg = g->max_col_deg;
     if (!((cdeg == 6 && vdeg == 3) || (cdeg == 4 && vdeg == 2) || (cdeg == 8 && vdeg == 4))) return false;
@@ -374,6 +393,7 @@ static bool plan_regular(const qldpc_graph *g, int max_iter, RegPlan &P) {
     const int rst = (cdeg % 2 == 0) ? cdeg + 1 : cdeg;
     const int nq = (g->n + 3) / 4;
     int S = QLDPC_LB_T / ts;                           // 4 blocks per CU fill its 32 wave slots
+    if (force_S > 0 && force_S < S) S = force_S;
     auto layout = [&](int s) {
         P.offV = s * g->m * rst * 8;
         P.offE = P.offV + s * g->n * 8;
@@ -454,14 +474,16 @@ int mc_regular_launch(const qldpc_graph *g, int64_t B, const double *d_prior, in
                       bool nanfree, uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask,
                       void *d_cold, hipStream_t stream, const int32_t *d_shot_list, const int32_t *d_shot_count) {
     RegPlan P;
-    if (!plan_regular(g, max_iter, P)) { set_error("graph is not regular (6,3)/(4,2)/(8,4)"); return QLDPC_ERR_UNSUPPORTED; }
+    // a shot list holds the few shots the first iteration did not finish; their iteration counts vary from 2 to max_iter, and a workgroup waits
+    // for its slowest shot: fewer shots per workgroup there (mc_list_shots)
+    if (!plan_regular(g, max_iter, P, d_shot_list ? g_list_shots : 0)) { set_error("graph is not regular (6,3)/(4,2)/(8,4)"); return QLDPC_ERR_UNSUPPORTED; }
     RegArgs A;
     fill_common(g, P, A, B, d_prior, max_iter, d_alpha, 1.0, clip, flags);
     A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32); A.thr = thr; A.use_osd = use_osd; A.shot_begin = shot_begin;
     A.Lmask = d_Lmask; A.cold = reinterpret_cast<const RegCold *>(d_cold);
     A.shot_list = d_shot_list; A.shot_count = d_shot_count;
     // listed shots: a few percent of the batch at BASELINE's error rates -- a grid for B / 16 shots covers them in one or two rounds
-    const unsigned grid = d_shot_list ? persistent_grid(std::max<int64_t>(B / 16, 1), P.S) : persistent_grid(B, P.S);
+    const unsigned grid = d_shot_list ? persistent_grid(std::max<int64_t>(B / 16, 1), P.S) * (unsigned)(g_list_shots > 0 ? 4 : 1) : persistent_grid(B, P.S);
     return dispatch_reg<true>(P, A, false, nanfree, grid, stream);
 }
 

@@ -30,6 +30,7 @@ QLDPC_EXPORT int qldpc_set_option(const char *name, int value) {
     if (!std::strcmp(name, "mc_first_iteration")) { QLDPC_REQUIRE(value == 0 || value == 1, "mc_first_iteration: 0 or 1"); qldpc::g_opt_first = value; return QLDPC_OK; }
     if (!std::strcmp(name, "mc_tail_overlap")) { QLDPC_REQUIRE(value == 0 || value == 1, "mc_tail_overlap: 0 or 1"); qldpc::g_opt_tail = value; return QLDPC_OK; }
     if (!std::strcmp(name, "mc_first_bits")) { QLDPC_REQUIRE(value == 8 || value == 16 || value == 32, "mc_first_bits: 8, 16 or 32"); qldpc::mc_first_set_bits(value); return QLDPC_OK; }
+    if (!std::strcmp(name, "mc_list_shots")) { QLDPC_REQUIRE(value >= 0 && value <= 16, "mc_list_shots: 0 .. 16"); qldpc::regular_set_list_shots(value); return QLDPC_OK; }
     const bool wave_opt = !std::strcmp(name, "regular_kernel") || !std::strcmp(name, "wave_cpl") || !std::strcmp(name, "wave_rst") || !std::strcmp(name, "wave_grid");
 #ifdef QLDPC_EXPERIMENTS
     if (!std::strcmp(name, "regular_kernel")) { QLDPC_REQUIRE(value >= 0 && value <= 2, "regular_kernel: 0, 1 or 2"); qldpc::g_opt_kernel = value; return QLDPC_OK; }

@@ -18,6 +18,8 @@ ap.add_argument("--batch", type=int, default=1 << 20)
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--skip-parity", action="store_true")
 ap.add_argument("--bits", default="8,16,32")
+ap.add_argument("--list-shots", default="0", help="mc_list_shots settings to time, e.g. 0,1,2")
+ap.add_argument("--spread", default="1", help="mc_first_spread settings to time, e.g. 0,1")
 ap.add_argument("--overlap", default="1", help="mc_tail_overlap settings to time, e.g. 0,1")
 a = ap.parse_args()
 
@@ -40,8 +42,10 @@ for tag in a.codes.split(","):
                 if not np.array_equal(got, ref):
                     raise SystemExit(f"PARITY FAIL {tag} p={p} max_iter={mi} bits={bits}: first-iteration pipeline {got.tolist()} oracle {ref.tolist()}")
             print(f"{tag} p={p} max_iter={mi} shots={count}: first-iteration pipeline == full pipeline == oracle: {ref[:13].tolist()}", flush=True)
-    for (first, bits, ov) in [(0, 8, 1)] + [(1, int(x), int(o)) for x in a.bits.split(",") for o in a.overlap.split(",")]:
+    for (first, bits, ov, ls, sp) in [(0, 8, 1, 0, 1)] + [(1, int(x), int(o), int(l), int(q)) for x in a.bits.split(",") for o in a.overlap.split(",") for l in a.list_shots.split(",")
+                                       for q in a.spread.split(",")]:
         _lib.set_option("mc_tail_overlap", ov)
+        _lib.set_option("mc_list_shots", ls)
         _lib.set_option("mc_first_iteration", first)
         _lib.set_option("mc_first_bits", bits)
         plan = _lib.CodeCapacityPlan(g, c["Lx"], 0.005, max_iter=50, flags=0, batch=a.batch)
@@ -51,10 +55,12 @@ for tag in a.codes.split(","):
             plan.run(2, k * a.batch, a.batch)
         t = plan.read()
         dt = time.perf_counter() - t0
+        ms1 = plan.first_iteration_time()
         ms, nl = plan.kernel_time()
-        name = "full decoder on every shot" if not first else f"first iteration bit-sliced, {bits} shots per lane, overlap {ov}"
-        print(f"{tag} early-exit  {name:58s} decode {ms / nl:8.3f} ms/launch  pipeline {dt / a.steps * 1e3:8.3f} ms/step  -> "
+        name = "full decoder on every shot" if not first else f"first iteration bit-sliced, {bits} shots per lane, overlap {ov}, list shots {ls}, spread {sp}"
+        print(f"{tag} early-exit  {name:74s} decode {ms / nl:8.3f} ms/launch (first iteration {ms1 / nl:6.3f})  pipeline {dt / a.steps * 1e3:8.3f} ms/step  -> "
               f"{a.batch * a.steps / dt / 1e6:8.2f} Mshots/s  tally={t[:9].tolist()}", flush=True)
         plan.close()
 _lib.set_option("mc_first_iteration", 1)
 _lib.set_option("mc_first_bits", 8)
+_lib.set_option("mc_list_shots", 0)
