@@ -5,12 +5,11 @@
 # Copy what is to be judged into profiles/ afterwards (tools/profile_collect.py does it).
 TAG=${1:-r03}
 OUT=gpurun_out/$TAG
-mkdir -p "$OUT"
+mkdir -p "$OUT/pmc"
 export TMPDIR=/tmp
 set -o pipefail
 echo "[1] issue rates" && timeout -k 10 300 ./tools/microbench/build/issue_rate > "$OUT/issue_rate.txt" 2>&1
-echo "[2] OSD workload counts (timers build)" && timeout -k 10 300 python3 tools/kbench_circuit.py --timers --serial --trials 32768 --counts-out "$OUT/pmc/osd_counts.json.tmp" > "$OUT/kbench_circuit_timers.txt" 2>&1
-mkdir -p "$OUT/pmc" && [ -f "$OUT/pmc/osd_counts.json.tmp" ] && mv "$OUT/pmc/osd_counts.json.tmp" "$OUT/pmc/osd_counts.json"
+echo "[2] OSD workload counts (timers build)" && timeout -k 10 300 python3 tools/kbench_circuit.py --timers --serial --trials 32768 --counts-out "$OUT/pmc/osd_counts.json" > "$OUT/kbench_circuit_timers.txt" 2>&1
 echo "[3] PMC passes" && timeout -k 10 900 bash tools/pmc_passes.sh "$OUT/pmc" > "$OUT/pmc_passes.log" 2>&1
 python3 tools/pmc_summarise.py "$OUT/pmc" "$TAG" > "$OUT/pmc_summary.txt" 2>&1
 cp profiles/pmc.json "$OUT/pmc.json"; cp "profiles/${TAG}_pmc.txt" "$OUT/${TAG}_pmc.txt"
