@@ -186,9 +186,11 @@ def issue_roofline(entry, mix, units_per_launch, ms_per_launch, clock_mhz, floor
         out["code_object"] = {k: mix["code_object"].get(k) for k in ("vgpr_count", "sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size")}
         if floor_cycles_per_unit:
             out["efficiency"] = round(floor_cycles_per_unit / (per_unit * cpi), 4)          # algorithmic / issued issue-cycles
-    for k in ("SQ_WAIT_ANY_frac", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "lds_bank_conflict_frac", "lds_busy_frac", "valu_types"):
+    for k in ("SQ_WAIT_ANY_frac", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "lds_bank_conflict_frac", "valu_types"):
         if k in entry:
             out[k] = entry[k]
+    if entry.get("SQ_LDS_IDX_ACTIVE"):        # LDS-array cycles (PMC, incl. bank conflicts) per CU-cycle of this run: the second resource of these kernels
+        out["lds_busy_frac"] = round(entry["SQ_LDS_IDX_ACTIVE"] * (units_per_launch / entry["units_per_launch"]) / (256.0 * (clock or 2400.0) * 1e6 * secs), 4)
     tr = entry.get("hbm_bytes_per_launch")
     out["traffic"] = tr
     if tr is not None:

@@ -88,8 +88,6 @@ def main():
             e["lds_bank_conflict_frac"] = round(e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"], 4)
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
-        if e.get("SQ_LDS_IDX_ACTIVE") and e.get("SQ_BUSY_CYCLES"):
-            e["lds_busy_frac"] = round(e["SQ_LDS_IDX_ACTIVE"] / e["SQ_BUSY_CYCLES"] / 4.0, 4)          # LDS-array cycles / (SQ busy cycles x 4 arrays per SE sample)
         types = {c[len("SQ_INSTS_VALU_"):]: round(e[c] / units, 3) for c in e if c.startswith("SQ_INSTS_VALU_")}
         if types:
             e["valu_types"] = types                   # wave-instructions per unit by the hardware's own type counters (cross-check of the static mix)
