@@ -102,7 +102,9 @@ int qldpc_device_count(void);
  *   "mc_first_iteration"  reference-semantics Monte-Carlo plans: 1 (default) = bit-sliced first iteration (csrc/mc_first.hip) + the full decoder
  *                         on the shots it lists, 0 = the full decoder for every shot
  *   "mc_first_bits"       shots per lane of that kernel: 8 (default), 16, 32
- *   "mc_tail_overlap"     1 (default; read at plan creation) = OSD-0 + judge of a batch on a side stream beside the next batch's decode
+ *   "mc_tail_overlap"     read at plan creation: 1 (default) = whole batches on the plan's own streams so that the latency-bound pieces of one batch run
+ *                         beside the next batch's first kernel (3 streams for large batches under reference semantics, 8 for batches <= 32768; fixed-work
+ *                         plans with large batches keep the caller's stream), 2 = only OSD-0 + judge on a side stream, 0 = everything on the caller's stream
  *   "regular_kernel", "wave_cpl", "wave_rst", "wave_grid"  experiments build only: the wave-private decoder (csrc/minsum_wave.hip); the
  *                         product library accepts 0 and answers anything else with QLDPC_ERR_UNSUPPORTED */
 int qldpc_set_option(const char *name, int value);
@@ -207,10 +209,14 @@ typedef struct qldpc_cc_plan qldpc_cc_plan;
 int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t *L, double p, int max_iter, int alpha_mode,
                          double alpha_val, const double *alpha_seq, int alpha_len, double damping, double clip_llr,
                          int use_osd, int flags, int64_t batch, qldpc_cc_plan **out);
+/* _run only enqueues: on `stream`, or (option mc_tail_overlap >= 1: reference-semantics plans and plans with batch <= 32768) on streams the plan owns,
+ * which start behind everything `stream` held when _run was called; several batches are then in flight at once.  _read waits for `stream` and for
+ * the plan's own streams, then copies the tally: it is the only way results leave the plan. */
 int qldpc_cc_plan_run(qldpc_cc_plan *plan, uint64_t seed, int64_t shot_begin, int64_t count, void *stream);
 int qldpc_cc_plan_read(qldpc_cc_plan *plan, void *stream, int clear, int64_t *tally);
 /* time of the decode kernel launches enqueued since the last call, measured with hipEvents on the launch
- * stream (ms, summed) and their count; used by bench.py for the roofline line. */
+ * stream (ms, summed) and their count; used by bench.py for the roofline line.  With batches in flight on several streams the spans overlap (their
+ * sum exceeds the wall time and each contains its neighbours' work): bench.py takes kernel times from a plan created with mc_tail_overlap = 2. */
 int qldpc_cc_plan_kernel_time(qldpc_cc_plan *plan, double *ms_total, int64_t *launches);
 /* the part of that total spent in the bit-sliced first-iteration kernel of the reference-semantics pipeline (csrc/mc_first.hip; 0 for plans
  * that do not use it).  Call before qldpc_cc_plan_kernel_time, which resets both sums. */

@@ -116,6 +116,8 @@ using namespace qldpc;
 // ------------------------------------------------------------------------------------------ plan
 static const int64_t kFanBatch = 32768;
 static const int kFanLanes = 8;
+static int g_big_lanes = 3;
+namespace qldpc { void mc_set_big_lanes(int n) { g_big_lanes = n; } }
 
 struct qldpc_cc_plan {
     const qldpc_graph *g = nullptr;
@@ -236,9 +238,14 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
             return fail(rc);
         // (fixed-work plans with large batches keep everything on the caller's stream: beside a 13 ms decode launch the 0.1 ms tail gains nothing, and
         // measured concurrently it slows the persistent decode kernel by 5 %, profiles/r03_experiments.txt)
-        if (mc_tail_overlap_choice() == 1 && (!(flags & QLDPC_FLAG_FIXED_ITERS) || batch <= kFanBatch)) {
-            P->fan = batch <= kFanBatch;
-            const int nl = P->fan ? kFanLanes : (use_osd ? 2 : 1);
+        if (mc_tail_overlap_choice() >= 1 && (!(flags & QLDPC_FLAG_FIXED_ITERS) || batch <= kFanBatch)) {
+            // reference semantics with large batches: a batch is the first-iteration kernel (every CU, 0.18 ms) followed by latency-bound pieces -- the full
+            // decoder on the few listed shots (its time is the 50 iterations of the slowest shot: ~0.11 ms), OSD-0 and the judge.  Whole batches on
+            // a few (option mc_big_lanes, default 3) streams of their own let those pieces of batch k run beside the first-iteration kernel of batch k + 1 (option mc_tail_overlap = 2
+            // keeps the round-3a form: decode on the caller's stream, only OSD-0 + judge on a side stream)
+            const bool big_fan = !(flags & QLDPC_FLAG_FIXED_ITERS) && batch > kFanBatch && mc_tail_overlap_choice() == 1;
+            P->fan = batch <= kFanBatch || big_fan;
+            const int nl = P->fan ? (big_fan ? g_big_lanes : kFanLanes) : (use_osd ? 2 : 1);
             P->lanes.resize(nl);
             bool ok = true;
             for (int i = 1; i < nl; i++) {              // lane 0 = the plan's own buffers

@@ -187,17 +187,21 @@ def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, m
             if total_errs >= target_logical_errors:
                 break
         else:
-            local_tally = np.zeros(_lib.TALLY_SLOTS, np.int64)
-            for off in range(0, count, batch):                                      # batch by batch: an unsatisfied batch is redone with OSD-w
-                nb = min(batch, count - off)
-                plan.run(base_seed, done + begin + off, nb)
-                if osd_order > 0:
+            # The fused plan runs OSD-0, which IS the reference's OSD-w answer whenever it reproduces the syndrome (osd.py:27-29) -- every syndrome a
+            # circuit can produce.  So the whole range goes through at full speed (no host round trip between batches) and the unsatisfied counters
+            # are looked at once; only if a trial was left unsatisfied (foreign decoding matrices) is the range redone batch by batch with OSD-w.
+            if count:
+                plan.run(base_seed, done + begin, count)
+            local_tally = plan.read(clear=True)
+            if osd_order > 0 and (local_tally[T["unsat_z"]] or local_tally[T["unsat_x"]]):
+                local_tally = np.zeros(_lib.TALLY_SLOTS, np.int64)
+                for off in range(0, count, batch):
+                    nb = min(batch, count - off)
+                    plan.run(base_seed, done + begin + off, nb)
                     t = plan.read(clear=True)
                     if t[T["unsat_z"]] or t[T["unsat_x"]]:
                         t = osdw_batch(done + begin + off, nb)[1]
                     local_tally += t
-            if osd_order == 0:
-                local_tally = plan.read(clear=True)
             total += parallel.allreduce_tally(local_tally, device=device)           # engine.py:450-457
             done += this
     plan.close()

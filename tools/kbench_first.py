@@ -19,6 +19,7 @@ ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--skip-parity", action="store_true")
 ap.add_argument("--bits", default="8,16,32")
 ap.add_argument("--list-shots", default="0", help="mc_list_shots settings to time, e.g. 0,1,2")
+ap.add_argument("--lanes", default="3", help="mc_big_lanes settings to time, e.g. 2,3,4")
 ap.add_argument("--spread", default="1", help="mc_first_spread settings to time, e.g. 0,1")
 ap.add_argument("--overlap", default="1", help="mc_tail_overlap settings to time, e.g. 0,1")
 a = ap.parse_args()
@@ -43,7 +44,8 @@ for tag in a.codes.split(","):
                     raise SystemExit(f"PARITY FAIL {tag} p={p} max_iter={mi} bits={bits}: first-iteration pipeline {got.tolist()} oracle {ref.tolist()}")
             print(f"{tag} p={p} max_iter={mi} shots={count}: first-iteration pipeline == full pipeline == oracle: {ref[:13].tolist()}", flush=True)
     for (first, bits, ov, ls, sp) in [(0, 8, 1, 0, 1)] + [(1, int(x), int(o), int(l), int(q)) for x in a.bits.split(",") for o in a.overlap.split(",") for l in a.list_shots.split(",")
-                                       for q in a.spread.split(",")]:
+                                       for q in a.lanes.split(",")]:
+        _lib.set_option("mc_big_lanes", max(2, sp))
         _lib.set_option("mc_tail_overlap", ov)
         _lib.set_option("mc_list_shots", ls)
         _lib.set_option("mc_first_iteration", first)
@@ -57,7 +59,7 @@ for tag in a.codes.split(","):
         dt = time.perf_counter() - t0
         ms1 = plan.first_iteration_time()
         ms, nl = plan.kernel_time()
-        name = "full decoder on every shot" if not first else f"first iteration bit-sliced, {bits} shots per lane, overlap {ov}, list shots {ls}, spread {sp}"
+        name = "full decoder on every shot" if not first else f"first iteration bit-sliced, {bits} shots per lane, overlap {ov}, list shots {ls}, lanes {sp}"
         print(f"{tag} early-exit  {name:74s} decode {ms / nl:8.3f} ms/launch (first iteration {ms1 / nl:6.3f})  pipeline {dt / a.steps * 1e3:8.3f} ms/step  -> "
               f"{a.batch * a.steps / dt / 1e6:8.2f} Mshots/s  tally={t[:9].tolist()}", flush=True)
         plan.close()

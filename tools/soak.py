@@ -37,7 +37,7 @@ def fail(msg):
 
 t_end = time.time() + a.seconds
 t_note = time.time() + 60
-count = {"decode": 0, "tally": 0, "osd": 0, "circuit": 0, "stats": 0, "osdw": 0}
+count = {"decode": 0, "tally": 0, "plan": 0, "osd": 0, "circuit": 0, "stats": 0, "osdw": 0}
 gold = {}
 for t in ("circ72",):
     with np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", t + "_noise.npz")) as z:
@@ -63,7 +63,7 @@ while time.time() < t_end:
     if time.time() > t_note:
         print(f"  ... {count}", flush=True)          # progress line (a silent GPU job is taken to be hung)
         t_note = time.time() + 60
-    kind = rng.choice(["decode", "decode", "tally", "osd", "circuit", "stats", "osdw"])
+    kind = rng.choice(["decode", "decode", "tally", "plan", "osd", "circuit", "stats", "osdw"])
     if kind == "stats":                                   # estimator trial loops (f4): range, finite counts, both histograms
         tag = str(rng.choice(["bb72", "bb144", "steane", "bb90"]))
         c = codes[tag]; ip, ix, n = c["Hx_indptr"], c["Hx_indices"], int(c["n"])
@@ -165,6 +165,26 @@ while time.time() < t_end:
         for nm, x, y in zip(("err", "conv", "llr", "iter"), (out[0], out[1].astype(bool), out[2], out[3]), (ref[0], ref[1].astype(bool), ref[2], ref[3])):
             if not np.array_equal(x, y, equal_nan=True):
                 fail(f"decode {tag} B={B} p={p} mode={mode} alpha={alpha} damping={damping} clip={clip} iters={iters} flags={flags} vg={env} field={nm} seed={a.seed} n={count}")
+    elif kind == "plan":            # a plan over several batches: concurrent small batches / the side-stream tail, several run() calls before one read()
+        tag = str(rng.choice(["bb72", "bb90", "bb108", "bb144", "bb288"]))
+        c = codes[tag]; ip, ix, n = c["Hx_indptr"], c["Hx_indices"], int(c["n"])
+        g = graph(tag, ip, ix, n)
+        p = float(rng.choice([0.003, 0.01, 0.03, 0.08])); iters = int(rng.integers(1, 55)); use_osd = bool(rng.random() < 0.8)
+        batch = int(rng.choice([257, 1000, 4096, 30000, 40000])); seed = int(rng.integers(0, 2 ** 62))
+        flags = int(rng.choice([0, 0, L.FLAG_FIXED_ITERS]))
+        L.set_option("mc_first_iteration", int(rng.random() < 0.8)); L.set_option("mc_tail_overlap", int(rng.random() < 0.8))
+        plan = L.CodeCapacityPlan(g, c["Lx"], p, max_iter=iters, use_osd=use_osd, flags=flags, batch=batch)
+        want = np.zeros(16, np.int64); begin = int(rng.integers(0, 10 ** 9))
+        for _ in range(int(rng.integers(1, 4))):
+            N = int(rng.integers(1, 3 * batch + 2))
+            plan.run(seed, begin, N)
+            want += oracle.cc_sample_decode_tally(ip, ix, n, c["Lx"], p, seed, begin, N, max_iter=iters, use_osd=use_osd, threads=0)
+            begin += N
+        got = plan.read()
+        plan.close()
+        L.set_option("mc_first_iteration", 1); L.set_option("mc_tail_overlap", 1)
+        if not np.array_equal(got, want):
+            fail(f"plan {tag} p={p} batch={batch} seed={seed} iters={iters} osd={use_osd} flags={flags} got={got.tolist()} want={want.tolist()}")
     elif kind == "tally":
         tag = str(rng.choice(["bb72", "bb90", "bb108", "bb144", "bb288", "steane"]))
         c = codes[tag]; ip, ix, n = c["Hx_indptr"], c["Hx_indices"], int(c["n"])
