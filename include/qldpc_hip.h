@@ -59,6 +59,8 @@ extern "C" {
                                            literal one-wave-per-shot elimination */
 #define QLDPC_FLAG_WG_VGLOBAL 0x100     /* workgroup-per-shot decoder: posteriors in HBM/L2 even when they fit LDS (the large-graph form) */
 #define QLDPC_FLAG_WG_GENERIC 0x200     /* workgroup-per-shot decoder: the any-input kernel even for host-verified clean inputs */
+#define QLDPC_FLAG_OSD_REFORDER 0x80000 /* OSD-0, m <= 1024: every shot through the kernel that follows the reference's row choice at each pivot (by default
+                                          only the shots whose right-hand side lies outside the column space take it; the others cannot tell) */
 #define QLDPC_FLAG_OSD_UG 0x400         /* OSD-0: row transform in HBM/L2 even when it fits LDS (the m > 1024 form) */
 #define QLDPC_FLAG_OSD_GLOBAL 0x800     /* OSD-0: the literal global-memory elimination (general fallback) */
 #define QLDPC_FLAG_WG_ROWMAJOR 0x8000   /* workgroup-per-shot decoder: natural row / column order instead of the degree-sorted assignment */

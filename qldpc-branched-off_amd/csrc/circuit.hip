@@ -477,7 +477,7 @@ static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B,
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->clk_probe = (clk && sector == 0) ? clk + 2 * kClkSlots : nullptr;
-        rc = osd0_listed_launch(g, list.as<int32_t>(), count, syn.as<int8_t>(), llr.as<double>(), det.as<int8_t>(), nullptr,
+        rc = osd0_listed_launch(g, list.as<int32_t>(), count, B, syn.as<int8_t>(), llr.as<double>(), det.as<int8_t>(), nullptr,
                                 det.as<int8_t>(), P->flags, s);
         g->clk_probe = nullptr;
     }

@@ -123,7 +123,7 @@ struct qldpc_graph {
     // are protected in STREAM order: every user calls ws_acquire(stream) before its launches and ws_release(stream) after them, so a
     // launch on another stream first waits (hipStreamWaitEvent) for the previous user of the workspaces to finish.
     mutable std::mutex mu;
-    mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_misc, ws_queue, ws_list, ws_prior;
+    mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_misc, ws_queue, ws_list, ws_prior, ws_redo;
     mutable hipEvent_t ws_event = nullptr;
     mutable hipStream_t ws_stream = nullptr;
     mutable bool ws_used = false;

@@ -193,20 +193,20 @@ __global__ __launch_bounds__(1024) void osd0_kernel(OsdArgs P) {
     }
 }
 
-int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
                     const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
 
 static int osd0_global_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
                               const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream);
 
 // callers hold g->mu; the graph's device workspaces are handed over in stream order (common.h)
-int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
                        const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream) {
     if (g->m == 0 || g->n == 0) return QLDPC_OK;
     int rc = g->ws_acquire(stream);                 // (a no-op for a caller that already holds the workspaces on this stream)
     if (rc != QLDPC_OK) return rc;
     bool handled = false;           // LDS-resident kernels for m <= 4096; the global-memory kernel is the general fallback
-    rc = osd0_lds_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
+    rc = osd0_lds_launch(g, d_list, d_count, max_listed, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
     if (rc == QLDPC_OK && !handled) rc = osd0_global_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, stream);
     const int rel = g->ws_release(stream);          // always: a failing call may have enqueued launches the next stream has to wait for
     return rc != QLDPC_OK ? rc : rel;
@@ -542,7 +542,7 @@ QLDPC_EXPORT int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t 
     hipLaunchKernelGGL(iota_list_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, nullptr, B, dlist.as<int32_t>(), dcnt.as<int32_t>());
     {
         std::lock_guard<std::mutex> lk(g->mu);
-        rc = osd0_listed_launch(g, dlist.as<int32_t>(), dcnt.as<int32_t>(), ds.as<int8_t>(), dl.as<double>(), dh.as<int8_t>(),
+        rc = osd0_listed_launch(g, dlist.as<int32_t>(), dcnt.as<int32_t>(), B, ds.as<int8_t>(), dl.as<double>(), dh.as<int8_t>(),
                                 ordering ? dord.as<int32_t>() : nullptr, dsol.as<int8_t>(), flags, nullptr);
         if (rc == QLDPC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("OSD-0 kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = QLDPC_ERR_HIP; }
     }
@@ -574,7 +574,7 @@ QLDPC_EXPORT int qldpc_osd0_batch_dev(const qldpc_graph *g, int64_t B, const int
         hipLaunchKernelGGL(iota_list_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, list, cnt);
         d_select = list; d_select_count = cnt;
     }
-    return osd0_listed_launch(g, d_select, d_select_count, d_syndromes, d_llr, d_hard, d_ordering, d_solution, flags, s);
+    return osd0_listed_launch(g, d_select, d_select_count, B, d_syndromes, d_llr, d_hard, d_ordering, d_solution, flags, s);
 }
 
 // f1: batched performOSD_enhanced(order, max_combinations) (osd.py:5-77); order == 0 is qldpc_osd0_batch.
@@ -1167,7 +1167,10 @@ static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds, int fl
     return 0;
 }
 
-int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
+                   const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled);
+
+int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
                     const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled) {
     OsdLdsArgs P;
     size_t lds = 0;
@@ -1192,6 +1195,15 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
         if (rcp != QLDPC_OK || handled) return rcp;
     }
 #endif
+    if (!(flags & (QLDPC_FLAG_OSD_REFORDER | QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL | QLDPC_FLAG_OSD_P2WAVES |
+                   QLDPC_FLAG_OSD_P3SERIAL | QLDPC_FLAG_OSD_NOKILL))) {
+        // m <= 1024: the free-pivot kernel (osd_gj.hip) takes every shot; the ones it lists (right-hand side outside the column space, where the
+        // answer depends on the reference's row choice) go through the reference-order kernel below, behind it on the same stream
+        bool took = false;
+        const int rcg = osd0_gj_launch(g, d_list, d_count, max_listed, d_synd, d_llr, d_hard, d_ordering, d_solution, stream, took);
+        if (rcg != QLDPC_OK) return rcg;
+        if (took) { d_count = g->ws_redo.as<int32_t>(); d_list = d_count + 4; }
+    }
     const int mode = (flags & QLDPC_FLAG_OSD_GLOBAL) ? 0 : plan_osd_lds(g, P, lds, flags);
     if (mode == 0) return QLDPC_OK;
     if (g->gf2_rank < 0) g->gf2_rank = host_gf2_rank(g);      // callers hold g->mu

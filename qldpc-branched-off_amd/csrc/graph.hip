@@ -256,7 +256,7 @@ QLDPC_EXPORT void qldpc_graph_destroy(qldpc_graph *g) {
                     (void *)g->d_deg_of_col, (void *)g->d_ell_col_s, (void *)g->d_ell_var_s, (void *)g->d_identity})
         if (p) (void)hipFree(p);
     g->ws_prior.release();
-    g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_list.release();
+    g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_list.release(); g->ws_redo.release();
     for (auto &e : g->alpha_cache) { if (e.dev) (void)hipFree(e.dev); if (e.pinned) (void)hipHostFree(e.pinned); if (e.ready) (void)hipEventDestroy(e.ready); }
     if (g->ws_event) (void)hipEventDestroy(g->ws_event);
     if (g->pin) (void)hipHostFree(g->pin);

@@ -336,7 +336,7 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
                 }
                 const qldpc_graph *go = (Ln && Ln->g) ? Ln->g : g;
                 std::lock_guard<std::mutex> lk(go->mu);
-                if ((rc = osd0_listed_launch(go, b_list.as<int32_t>(), b_count.as<int32_t>(), b_synd.as<int8_t>(), b_llr.as<double>(),
+                if ((rc = osd0_listed_launch(go, b_list.as<int32_t>(), b_count.as<int32_t>(), B, b_synd.as<int8_t>(), b_llr.as<double>(),
                                              b_dec.as<int8_t>(), nullptr, b_dec.as<int8_t>(), P->flags, ts)) != QLDPC_OK)
                     return rc;
                 if ((rc = judge_failed_launch(g, b_count.as<int32_t>(), P->d_Lmask.as<uint64_t>(), b_err.as<int8_t>(), b_synd.as<int8_t>(),
@@ -370,7 +370,7 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
             QLDPC_HIP_TRY(hipGetLastError());
             {
                 std::lock_guard<std::mutex> lk(g->mu);
-                rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), P->d_synd.as<int8_t>(), P->d_llr.as<double>(),
+                rc = osd0_listed_launch(g, P->d_list.as<int32_t>(), P->d_count.as<int32_t>(), B, P->d_synd.as<int8_t>(), P->d_llr.as<double>(),
                                         P->d_dec.as<int8_t>(), nullptr, P->d_dec.as<int8_t>(), P->flags, s);
             }
             if (rc != QLDPC_OK) return rc;

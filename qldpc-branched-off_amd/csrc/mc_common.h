@@ -61,8 +61,8 @@ int build_alpha_table(int max_iter, int alpha_mode, double alpha_val, const doub
 int gf2_spmv_launch(const qldpc_graph *g, int64_t B, const int8_t *d_vec, int8_t *d_out, hipStream_t stream);
 
 // OSD-0 on the shots listed in d_list[0 .. *d_count) (device-resident count: no host sync).  d_ordering may be NULL
-// (stable ascending |llr|); otherwise int32[B][n] indexed by shot.  solution may alias hard.
-int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
+// (stable ascending |llr|); otherwise int32[B][n] indexed by shot.  solution may alias hard.  max_listed: an upper bound of *d_count.
+int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
                        const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream);
 
 }  // namespace qldpc

@@ -1,0 +1,397 @@
+// OSD-0 (a9, reference src/decoding/osd.py:5-29 + gf2_elimination_packed_core, src/decoding/kernels.py:48-96) for matrices with
+// m <= 1024 rows: one workgroup per shot, the row transform in LDS, FREE pivot rows -- the round-3 kernel.
+//
+// What the reference computes: the columns of H in ascending-|llr| order, a Gauss-Jordan elimination that takes the first non-zero row at or
+// below the diagonal as the pivot (kernels.py:71-82), and e[pivot column] = reduced rhs at the pivot row (osd.py:19-25).  What that IS:
+//   S = the columns that are independent of the columns before them in that order (a property of the column spaces only), and
+//   e_S = the solution of H_S e_S = b, unique because H_S has full column rank.
+// Neither depends on WHICH row of a column is taken as its pivot as long as b lies in the column space of H -- always the case for a
+// syndrome that an error produced.  This kernel therefore takes any unused row (the first set bit of the reduced column among the rows that
+// have not pivoted yet) and drops everything the reference's row choice costs a formulation that tracks it: no row swaps (no position
+// table, no second tested bit per operation), and -- the larger gain -- the operations of a block of 16 columns become ORDER-FREE:
+//   * state: U = T^T for the accumulated row transform T (current rows = T * original rows), m x m bits in LDS; row m is all zero (padding
+//     target of short columns), row m + 1 carries the right-hand side b = s + H hard (it transforms like a column);
+//   * the reduced form of a sparse column h (<= 6 ones) is XOR_{i in supp h} U[i]; it pivots iff it has a one in an unused row;
+//   * a block of 16 columns is resolved in ONE wave on registers (lane = 4 w + g holds word w of columns g, 4 + g, 8 + g, 12 + g) by a full
+//     Gauss-Jordan among the 16: a pivot step clears the pivot row pp_k from EVERY other column of the block, the finished ones included.
+//     The finished columns then are the columns C_k of the block's composite transform  E = I + sum_k C_k e_{pp_k}^T,  i.e.
+//         new row p' of T = old row p' + sum_{k : C_k[p']} old row pp_k      <=>      U[q] ^= XOR_{k : bit pp_k of U[q]} C_k
+//     with the bits tested on the OLD U[q]: a thread owning row q reads its 16 bits, and whatever is set selects masks to add, in any order
+//     (the reference-order kernel in gf2.hip replays the 16 operations one after the other per row, tracking two bits per operation);
+//   * dependent columns are dropped in parallel batches and the sweep stops at rank(H), as in the reference-order kernel.
+// A right-hand side outside the column space (only a caller's own syndromes can be) shows as a one of the reduced b in an unused row; such a
+// shot is put on a list and solved by the reference-order kernel (gf2.hip) afterwards, so every input still gets the reference's answer.
+#include "common.h"
+#include "mc_common.h"
+#include "osd_common.h"
+
+#include <algorithm>
+
+namespace qldpc {
+
+struct OsdGjArgs {
+    int m, n, mw, rankH, K, cdeg;
+    const int32_t *colptr, *rowidx, *indptr, *indices;
+    const int32_t *list, *count;
+    const int8_t *synd; const double *llr; const int8_t *hard; const int32_t *ordering;
+    int8_t *solution;
+    uint16_t *ordws;               // [grid][n] sorted column order of the shot in flight (global, L2-resident)
+    int *queue;                    // next list entry to process (zeroed before the launch)
+    int32_t *redo_list, *redo_count;   // shots whose right-hand side is outside the column space (count zeroed before the launch)
+    unsigned long long *clk, *dbg;
+    int offIdx, offAlive, offRows, offPc, offPr, offR, offBlk, offUsed;
+};
+
+int host_gf2_rank(const qldpc_graph *g);
+
+constexpr int kGjBlock = 16;
+
+struct GjBlock {
+    unsigned long long X[4];       // the lane's word of columns g, 4 + g, 8 + g, 12 + g
+    unsigned long long live;       // rows of the lane's word that have not pivoted
+    int nops, maxops;
+    uint32_t depmask, pivmask;     // columns found dependent / columns that pivoted
+    int oppv;                      // lane t: pivot row of column t
+};
+
+// one pivot step of the block (column T): any unused row with a one, then that row cleared from every other column of the block
+template <int T>
+__device__ __forceinline__ void gj_pivot_step(GjBlock &S, int lane) {
+    constexpr int IT = T >> 2, GT = T & 3;
+    const int g = lane & 3, w = lane >> 2;
+    const unsigned long long owners = 0x1111111111111111ull << GT;
+    const unsigned long long mword = S.X[IT] & S.live;
+    const unsigned long long bal = __ballot(mword != 0ull) & owners;
+    if (bal == 0ull) { S.depmask |= 1u << T; return; }                                      // in the span of the pivots so far
+    const int src = __builtin_ctzll(bal);
+    const unsigned long long pword = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), src) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, src);
+    const int wp = src >> 2, pb = __builtin_ctzll(pword), pp = wp * 64 + pb;
+    const unsigned long long pl = (w == wp) ? (1ull << pb) : 0ull;
+    const unsigned long long rm = S.X[IT] & ~pl;                                            // lanes g == GT: the column without its pivot bit
+    const unsigned long long rmq = quad_bcast<GT>(rm);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned long long x = S.X[i];
+        const uint32_t np = (uint32_t)(__ballot((x & pl) != 0ull) >> (4 * wp));             // bit g: row pp of column 4 i + g
+        const int fp = __builtin_amdgcn_sbfe((int)np, g, 1);                                // 0 / -1
+        const unsigned long long add = sext64(fp) & rmq;
+        S.X[i] = x ^ ((i == IT && g == GT) ? pl : add);                                     // the pivot column itself only loses its pivot bit
+    }
+    S.live &= ~pl;
+    const int ppu = __builtin_amdgcn_readfirstlane(pp);
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(S.oppv) : "s"(ppu), "n"(T));          // lane t of oppv: pivot row of column t
+    S.pivmask |= 1u << T;
+    S.nops++;
+}
+
+__global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
+    extern __shared__ unsigned char lds[];
+    const int m = P.m, n = P.n, mw = P.mw, K = P.K, cd = P.cdeg, tid = threadIdx.x, T = blockDim.x;
+    unsigned long long *U = reinterpret_cast<unsigned long long *>(lds);
+    uint16_t *sidx = reinterpret_cast<uint16_t *>(lds + P.offIdx);         // [K] columns of the current chunk
+    uint8_t *alive = reinterpret_cast<uint8_t *>(lds + P.offAlive);        // [K]
+    uint16_t *colrows = reinterpret_cast<uint16_t *>(lds + P.offRows);     // [K][cd] supports
+    uint16_t *pvcol = reinterpret_cast<uint16_t *>(lds + P.offPc);         // [m] column of pivot t
+    uint16_t *pvrow = reinterpret_cast<uint16_t *>(lds + P.offPr);         // [m] row of pivot t
+    unsigned long long *R = reinterpret_cast<unsigned long long *>(lds + P.offR);       // [16][mw] reduced columns -> composite masks
+    unsigned long long *usedw = reinterpret_cast<unsigned long long *>(lds + P.offUsed); // [2][16] rows that have pivoted, by block parity
+    int *blk = reinterpret_cast<int *>(lds + P.offBlk);                    // [0] nb, [1] pivot mask, [2] anydep, [3] next c; [4..] cols[16], opp[16]
+    int *bcol = blk + 4, *opp = bcol + kGjBlock;
+    int *s_item = opp + kGjBlock;
+    uint16_t *ordw = P.ordws + (size_t)blockIdx.x * n;
+    const int brow = m + 1;
+    auto uix = [&](int q, int w) -> int { return uswz(q, w, mw); };
+
+    const int total = *P.count;
+    const ClkStamp clk0 = clk_begin(P.clk);
+    for (;;) {
+        if (tid == 0) *s_item = atomicAdd(P.queue, 1);
+        __syncthreads();
+        const int item = *s_item;
+        if (item >= total) break;
+        const int64_t shot = P.list[item];
+        const double *llr = P.llr + shot * n;
+        const int8_t *hard = P.hard + shot * n, *synd = P.synd + shot * m;
+        int8_t *sol = P.solution + shot * n;
+        const long long t_start = OSD_CLOCK();
+        if (!P.ordering) {                                                   // column order: ascending |llr| (osd.py:11-12), ties by index
+            unsigned long long *keys = reinterpret_cast<unsigned long long *>(lds);
+            uint16_t *pa = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8), *pb = pa + n;
+            unsigned *cnt = reinterpret_cast<unsigned *>(lds + (((size_t)n * 12 + 15) & ~(size_t)15));
+            osd_radix_sort(llr, n, keys, pa, pb, cnt, ordw);
+        }
+        // ---- init: T = I, b = s + H hard (osd.py:8-9) ----
+        for (int t = tid; t < (m + 2) * mw; t += T) U[t] = 0ull;
+        if (tid < 32) {                                                      // rows >= m of the last word never pivot
+            const int w = tid & 15;
+            usedw[tid] = (w >= mw) ? ~0ull : ((w == mw - 1 && (m & 63)) ? (~0ull << (m & 63)) : 0ull);
+        }
+        __syncthreads();
+        for (int r = tid; r < m; r += T) {
+            U[uix(r, r >> 6)] = 1ull << (r & 63);
+            int sy = synd[r] & 1;
+            for (int e = P.indptr[r]; e < P.indptr[r + 1]; e++) sy ^= hard[P.indices[e]] & 1;
+            if (sy) atomicOr(&U[uix(brow, r >> 6)], 1ull << (r & 63));
+        }
+        __syncthreads();
+        int row = 0, par = 0;                                                // pivots so far; parity of the block count (usedw buffer in force)
+        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0;
+        const long long t_sorted = OSD_CLOCK();
+        bool finished = (P.rankH == 0);
+        for (int base = 0; base < n && !finished; base += K) {
+            const int L = min(K, n - base);
+            d_chunks++;
+            for (int c = tid; c < L; c += T) {
+                sidx[c] = P.ordering ? (uint16_t)P.ordering[shot * n + base + c] : ordw[base + c];
+                alive[c] = 1;
+            }
+            if (tid == 0) blk[3] = 0;
+            __syncthreads();
+            for (int t = tid; t < L * cd; t += T) {                          // supports of the chunk's columns -> LDS
+                const int c = t / cd, d = t - c * cd, j = sidx[c];
+                const int k = P.colptr[j] + d;
+                colrows[t] = (k < P.colptr[j + 1]) ? (uint16_t)P.rowidx[k] : (uint16_t)m;          // row m of U is all zero
+            }
+            __syncthreads();
+            // drops every still-alive column of the chunk from c0 on that lies in the span of the pivots so far (one thread per column);
+            // `used` must be the buffer that matches the state of U
+            auto kill_pass = [&](int c0, int t0, int tstride, const unsigned long long *used) {
+                for (int c2 = c0 + t0; c2 < L; c2 += tstride) {
+                    if (!alive[c2]) continue;
+                    const uint16_t *cr2 = colrows + c2 * cd;
+                    int rr[8];
+#pragma unroll
+                    for (int d = 0; d < 8; d++) rr[d] = (d < cd) ? (int)cr2[d] : m;
+                    unsigned long long any = 0ull;
+                    for (int w = 0; w < mw; w++) {
+                        unsigned long long xs[8];
+#pragma unroll
+                        for (int d = 0; d < 8; d++) xs[d] = U[uix(rr[d], w)];
+                        unsigned long long x = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
+                        for (int d = 8; d < cd; d++) x ^= U[uix(cr2[d], w)];
+                        any |= x & ~used[w];
+                    }
+                    if (!any) alive[c2] = 0;
+                }
+            };
+            bool kill_due = false;
+            if (row > 0) {                                                   // a fresh chunk late in the sweep is mostly dependent columns
+                long long tk = OSD_CLOCK();
+                d_kills++;
+                kill_pass(0, tid, T, usedw + 16 * par);
+                __syncthreads();
+                c_kill += OSD_CLOCK() - tk;
+            }
+            while (true) {
+                if (tid < 64) {                                              // wave 0 collects the next alive columns of the chunk (ballot scan)
+                    int c = blk[3], nbc = 0;
+                    while (c < L && nbc < kGjBlock) {
+                        const int cc = c + tid;
+                        const bool al = (cc < L) && alive[cc];
+                        const unsigned long long bal = __ballot(al);
+                        const int before = __builtin_popcountll(bal & ((1ull << tid) - 1ull));
+                        if (al && nbc + before < kGjBlock) bcol[nbc + before] = cc;
+                        const int got = __builtin_popcountll(bal);
+                        if (nbc + got >= kGjBlock) {                          // stop right behind the column that filled the block
+                            int need = kGjBlock - nbc;
+                            unsigned long long bb = bal;
+                            int lastpos = 0;
+                            while (need-- > 0) { lastpos = __builtin_ctzll(bb); bb &= bb - 1; }
+                            c += lastpos + 1; nbc = kGjBlock;
+                        } else { nbc += got; c += 64; }
+                    }
+                    if (c > L) c = L;
+                    if (tid == 0) { blk[0] = nbc; blk[1] = 0; blk[2] = 0; blk[3] = c; }
+                }
+                __syncthreads();
+                const int nb = blk[0];
+                if (nb == 0) break;
+                d_blocks++; d_cols += nb;
+                long long tp = OSD_CLOCK();
+                // ---- phase 1: reduced columns R[t] = XOR of U rows ----
+                for (int x = tid; x < nb * mw; x += T) {
+                    const int t = x / mw, w = x - t * mw;
+                    const uint16_t *cr = colrows + bcol[t] * cd;
+                    int rr[8];
+                    unsigned long long xs[8];
+#pragma unroll
+                    for (int d = 0; d < 8; d++) rr[d] = (d < cd) ? (int)cr[d] : m;
+#pragma unroll
+                    for (int d = 0; d < 8; d++) xs[d] = U[uix(rr[d], w)];
+                    unsigned long long acc = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
+                    for (int d = 8; d < cd; d++) acc ^= U[uix(cr[d], w)];
+                    R[t * mw + w] = acc;
+                }
+                __syncthreads();
+                c_p1 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
+                // ---- phase 2: the block's pivots and composite masks, wave 0 on registers; the other waves run a due dependent-column test ----
+                const unsigned long long *used_now = usedw + 16 * par;
+                unsigned long long *used_next = usedw + 16 * (par ^ 1);
+                if (tid < 64) {
+                    const int lane = tid, g = lane & 3, w = lane >> 2;
+                    GjBlock S;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) S.X[i] = (4 * i + g < nb && w < mw) ? R[(4 * i + g) * mw + w] : 0ull;
+                    S.live = ~used_now[w];
+                    S.nops = 0; S.maxops = P.rankH - row; S.depmask = 0u; S.pivmask = 0u; S.oppv = 0;
+#define QLDPC_GSTEP(TT) if (TT < nb && S.nops < S.maxops) gj_pivot_step<TT>(S, lane);
+                    QLDPC_GSTEP(0) QLDPC_GSTEP(1) QLDPC_GSTEP(2) QLDPC_GSTEP(3) QLDPC_GSTEP(4) QLDPC_GSTEP(5) QLDPC_GSTEP(6) QLDPC_GSTEP(7)
+                    QLDPC_GSTEP(8) QLDPC_GSTEP(9) QLDPC_GSTEP(10) QLDPC_GSTEP(11) QLDPC_GSTEP(12) QLDPC_GSTEP(13) QLDPC_GSTEP(14) QLDPC_GSTEP(15)
+#undef QLDPC_GSTEP
+#pragma unroll
+                    for (int i = 0; i < 4; i++) if (4 * i + g < nb && w < mw) R[(4 * i + g) * mw + w] = S.X[i];
+                    if (g == 0) used_next[w] = ~S.live;
+                    if (lane < 16) opp[lane] = S.oppv;
+                    if (lane < 16 && ((S.pivmask >> lane) & 1u)) {
+                        const int t = row + __builtin_popcount(S.pivmask & ((1u << lane) - 1u));
+                        pvcol[t] = sidx[bcol[lane]]; pvrow[t] = (uint16_t)S.oppv;
+                    }
+                    if (lane < nb && ((S.depmask >> lane) & 1u)) alive[bcol[lane]] = 0;
+                    if (lane == 0) { blk[1] = (int)S.pivmask; blk[2] = (S.depmask != 0u) ? 1 : 0; }
+                } else if (kill_due) {
+                    kill_pass(blk[3], tid - 64, T - 64, used_now);
+                }
+                if (kill_due) { d_kills++; kill_due = false; }
+                __syncthreads();
+                const uint32_t valid = (uint32_t)blk[1];                     // columns of the block that pivoted
+                const int nops = __builtin_popcount(valid), anydep = blk[2];
+                par ^= 1;
+                c_p2 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
+                // ---- phase 3: U[q] ^= XOR_{k : bit pp_k of U[q]} C_k for every row q (and for b) ----
+                if (nops > 0) {
+                    int ppv = opp[tid & 15];                                 // column k's pivot row sits in lane k of every 16
+                    asm volatile("" : "+v"(ppv));
+                    const bool strided = (mw == 16);
+                    for (int qb = 0; qb < m + 2; qb += T) {
+                        const int q = strided ? qb + ((tid & 63) << 4) + (((tid >> 6) + tid) & 15) : qb + tid;
+                        const bool act = (q < m + 2) && (q != m);
+                        const int qq = act ? q : m;
+                        unsigned long long *rowbase = U + qq * mw;
+                        const int swz = (mw == 16) ? ((qq >> 3) & 14) : 0;
+                        const uint32_t *row32 = reinterpret_cast<const uint32_t *>(rowbase);
+                        uint32_t Pw[16], s0 = 0u;
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const int pk = ((valid >> k) & 1u) ? __builtin_amdgcn_readlane(ppv, k) : 0;
+                            Pw[k] = row32[2 * ((pk >> 6) ^ swz) + ((pk >> 5) & 1)];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const int pk = __builtin_amdgcn_readlane(ppv, k);
+                            s0 |= ((Pw[k] >> (pk & 31)) & 1u) << k;
+                        }
+                        s0 &= valid;
+                        if (!act) s0 = 0u;
+                        uint32_t x = s0;                                     // OR over the wave
+                        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+                        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);        // quad_perm [2,3,0,1]
+                        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);       // row_half_mirror
+                        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);       // row_mirror
+                        uint32_t wtb = (uint32_t)__builtin_amdgcn_readlane((int)x, 0) | (uint32_t)__builtin_amdgcn_readlane((int)x, 16) |
+                                       (uint32_t)__builtin_amdgcn_readlane((int)x, 32) | (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+                        while (wtb != 0u) {
+                            const int k = __builtin_ctz(wtb);
+                            wtb &= wtb - 1u;
+                            const unsigned long long *mk = R + k * mw;
+                            if ((s0 >> k) & 1u) {
+                                if (mw == 16) {                              // all reads in flight before the first XOR
+                                    ulonglong2 u[8], k2[8];
+                                    ulonglong2 *Uq = reinterpret_cast<ulonglong2 *>(rowbase);
+                                    const ulonglong2 *mk2 = reinterpret_cast<const ulonglong2 *>(mk);
+                                    const int sz = swz >> 1;
+#pragma unroll
+                                    for (int w = 0; w < 8; w++) u[w] = Uq[w ^ sz];
+#pragma unroll
+                                    for (int w = 0; w < 8; w++) k2[w] = mk2[w];
+#pragma unroll
+                                    for (int w = 0; w < 8; w++) { u[w].x ^= k2[w].x; u[w].y ^= k2[w].y; }
+#pragma unroll
+                                    for (int w = 0; w < 8; w++) Uq[w ^ sz] = u[w];
+                                } else {
+                                    for (int w = 0; w < mw; w++) rowbase[w] ^= mk[w];
+                                }
+                            }
+                        }
+                    }
+                }
+                row += nops;
+                __syncthreads();
+                c_p3 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
+                if (row >= P.rankH || row >= m) { finished = true; break; }
+                if (anydep) kill_due = true;                                 // done by the idle waves beside the next block's pivot chain
+            }
+            __syncthreads();      // nobody may refill alive[]/sidx[] while others still use them
+        }
+        if (P.dbg && tid == 0) {
+            atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)row);
+            atomicAdd(&P.dbg[4], (unsigned long long)(OSD_CLOCK() - t_start)); atomicAdd(&P.dbg[5], d_kills); atomicAdd(&P.dbg[6], d_blocks);
+            atomicAdd(&P.dbg[8], (unsigned long long)(t_sorted - t_start)); atomicAdd(&P.dbg[9], c_p1); atomicAdd(&P.dbg[10], c_p2); atomicAdd(&P.dbg[11], c_p3);
+            atomicAdd(&P.dbg[12], c_kill);
+        }
+        // ---- back-fill (osd.py:19-25): e[pivot col] = reduced rhs at the pivot row; solution = (hard + e) % 2 ----
+        __syncthreads();
+        if (sol != hard) for (int j = tid; j < n; j += T) sol[j] = hard[j];
+        if (tid == 0) {                                                      // b outside the column space: a one of the reduced b in an unused row
+            const unsigned long long *used = usedw + 16 * par;
+            unsigned long long bad = 0ull;
+            for (int w = 0; w < mw; w++) bad |= U[uix(brow, w)] & ~used[w];
+            if (bad) P.redo_list[atomicAdd(P.redo_count, 1)] = (int32_t)shot;
+        }
+        __syncthreads();
+        for (int t = tid; t < row; t += T) {
+            const int j = pvcol[t], pr = pvrow[t];
+            const int8_t bbit = (int8_t)((U[uix(brow, pr >> 6)] >> (pr & 63)) & 1ull);
+            sol[j] = (int8_t)((hard[j] ^ bbit) & 1);
+        }
+        __syncthreads();
+    }
+    clk_end(P.clk, clk0);
+}
+
+// handled = true when this kernel took the shots.  The shots it could not answer (right-hand side outside the column space) are left in
+// g->ws_redo ([0] count, [4..] shot indices) for the reference-order kernel, which the caller launches behind this one on the same stream.
+int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
+                   const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled) {
+    handled = false;
+    if (g->m > 1024 || g->m < 1 || g->n >= 65535 || g->n < 1) return QLDPC_OK;
+    OsdGjArgs P;
+    P.m = g->m; P.n = g->n; P.mw = (g->m + 63) / 64; P.K = 1024; P.cdeg = std::max(g->max_col_deg, 1);
+    const size_t sort_cnt = (size_t)256 * 16 * 4 + 16 * 4 + 64;
+    size_t off = std::max((size_t)(g->m + 2) * P.mw * 8, (size_t)g->n * 12 + 16 + sort_cnt);       // U, aliased by the sort scratch
+    off = (size_t)round_up((int64_t)off, 16);
+    P.offIdx = (int)off; off += (size_t)P.K * 2;
+    P.offAlive = (int)off; off += (size_t)P.K;
+    P.offRows = (int)off; off += (size_t)round_up((int64_t)P.K * P.cdeg * 2, 8);
+    P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
+    P.offPr = (int)off; off += round_up((int64_t)g->m * 2, 8);
+    P.offR = (int)off; off += (size_t)kGjBlock * P.mw * 8;
+    P.offUsed = (int)off; off += 32 * 8;
+    P.offBlk = (int)off; off += (4 + 3 * kGjBlock + 4) * 4;
+    const size_t lds = off + 16;
+    if (lds > 160 * 1024) return QLDPC_OK;
+    if (g->gf2_rank < 0) g->gf2_rank = host_gf2_rank(g);      // callers hold g->mu
+    P.rankH = g->gf2_rank;
+    const int grid = 512;
+    int rc = g->ws_misc.ensure((size_t)round_up((int64_t)grid * g->n * 2 + 64, 16));
+    if (rc != QLDPC_OK) return rc;
+    if ((rc = g->ws_redo.ensure((size_t)(max_listed + 4) * 4)) != QLDPC_OK) return rc;
+    if ((rc = g->ws_queue.ensure(16)) != QLDPC_OK) return rc;
+    P.ordws = g->ws_misc.as<uint16_t>();
+    P.colptr = g->d_colptr; P.rowidx = g->d_rowidx; P.indptr = g->d_indptr; P.indices = g->d_indices;
+    P.list = d_list; P.count = d_count; P.synd = d_synd; P.llr = d_llr; P.hard = d_hard; P.ordering = d_ordering; P.solution = d_solution;
+    P.clk = g->clk_probe;
+    P.dbg = osd_timer_buffer();
+    P.queue = g->ws_queue.as<int>() + 3;
+    P.redo_count = g->ws_redo.as<int32_t>(); P.redo_list = P.redo_count + 4;
+    QLDPC_HIP_TRY(hipMemsetAsync(P.queue, 0, 4, stream));
+    QLDPC_HIP_TRY(hipMemsetAsync(P.redo_count, 0, 4, stream));
+    const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m + 2, 256), 64));
+    if ((rc = ensure_max_lds(g->device, reinterpret_cast<const void *>(osd0_gj_kernel), 160 * 1024)) != QLDPC_OK) return rc;
+    hipLaunchKernelGGL(osd0_gj_kernel, dim3(grid), dim3(block), lds, stream, P);
+    QLDPC_HIP_TRY(hipGetLastError());
+    handled = true;
+    return QLDPC_OK;
+}
+
+}  // namespace qldpc

@@ -149,7 +149,7 @@ def test_circuit_level_golden(Lb, golden, oracle, tag):
             assert np.array_equal(sol2, ref2)
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
             # the general global-memory OSD kernel (used when m > 1024) must agree with the LDS-resident one
-            for kfl in for_build(L, (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_P2WAVES, L.FLAG_OSD_P3SERIAL)):   # ... and the other forms of the LDS kernel
+            for kfl in for_build(L, (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_REFORDER, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_P2WAVES, L.FLAG_OSD_P3SERIAL)):   # ... and the other forms of the LDS kernel
                 sol3 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, flags=kfl)
                 sol4 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0,
                                            ordering=g[f"{s}_osd_ordering"][t], flags=kfl)
@@ -1095,7 +1095,7 @@ def test_random_matrices_osd0_all_kernels(Lb, oracle, monkeypatch):
         hard = (rng.random((B, n)) < 0.1).astype(np.int8)
         want = np.stack([oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)])
         # (0 = the one-wave literal elimination for m <= 128, n <= 1024, else the transform kernel; FLAG_OSD_LDS forces the latter)
-        for env in for_build(L, (0, L.FLAG_OSD_LDS, L.FLAG_OSD_LDS | L.FLAG_OSD_P2WAVES, L.FLAG_OSD_LDS | L.FLAG_OSD_P3SERIAL, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD,
+        for env in for_build(L, (0, L.FLAG_OSD_LDS, L.FLAG_OSD_REFORDER, L.FLAG_OSD_LDS | L.FLAG_OSD_REFORDER, L.FLAG_OSD_LDS | L.FLAG_OSD_P2WAVES, L.FLAG_OSD_LDS | L.FLAG_OSD_P3SERIAL, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD,
                                  L.FLAG_OSD_PIPED, L.FLAG_OSD_NOKILL)):
             sol = L.osd0_batch(graph, synd, llr, hard, flags=env)
             assert np.array_equal(sol, want), (gi, env, np.flatnonzero((sol != want).any(1)))
