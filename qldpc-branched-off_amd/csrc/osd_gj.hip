@@ -32,6 +32,7 @@ namespace qldpc {
 struct OsdGjArgs {
     int m, n, mw, rankH, K, cdeg;
     const int32_t *colptr, *rowidx, *indptr, *indices;
+    const uint16_t *ell_col; const uint8_t *deg_of_row;   // slot-major row view ([slot][m] columns, [m] degrees) or NULL
     const int32_t *list, *count;
     const int8_t *synd; const double *llr; const int8_t *hard; const int32_t *ordering;
     int8_t *solution;
@@ -45,6 +46,10 @@ struct OsdGjArgs {
 int host_gf2_rank(const qldpc_graph *g);
 
 constexpr int kGjBlock = 16;
+#ifndef QLDPC_GJ_KILLWINDOW
+#define QLDPC_GJ_KILLWINDOW 240
+#endif
+constexpr int kGjKillWindow = QLDPC_GJ_KILLWINDOW;      // columns behind a block that its dependent-column test covers
 
 struct GjBlock {
     unsigned long long X[4];       // the lane's word of columns g, 4 + g, 8 + g, 12 + g
@@ -55,6 +60,7 @@ struct GjBlock {
 };
 
 // one pivot step of the block (column T): any unused row with a one, then that row cleared from every other column of the block
+// (the caller's control flow is wave-uniform: every condition below is a scalar branch)
 template <int T>
 __device__ __forceinline__ void gj_pivot_step(GjBlock &S, int lane) {
     constexpr int IT = T >> 2, GT = T & 3;
@@ -64,9 +70,14 @@ __device__ __forceinline__ void gj_pivot_step(GjBlock &S, int lane) {
     const unsigned long long bal = __ballot(mword != 0ull) & owners;
     if (bal == 0ull) { S.depmask |= 1u << T; return; }                                      // in the span of the pivots so far
     const int src = __builtin_ctzll(bal);
+#ifdef QLDPC_GJ_FFBL
+    const int pbv = __builtin_ctzll(mword | (1ull << 63));                                  // every lane's own first live one: off the scalar chain
+    const int wp = src >> 2, pb = __builtin_amdgcn_readlane(pbv, src), pp = wp * 64 + pb;
+#else
     const unsigned long long pword = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), src) << 32) |
                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, src);
     const int wp = src >> 2, pb = __builtin_ctzll(pword), pp = wp * 64 + pb;
+#endif
     const unsigned long long pl = (w == wp) ? (1ull << pb) : 0ull;
     const unsigned long long rm = S.X[IT] & ~pl;                                            // lanes g == GT: the column without its pivot bit
     const unsigned long long rmq = quad_bcast<GT>(rm);
@@ -79,15 +90,82 @@ __device__ __forceinline__ void gj_pivot_step(GjBlock &S, int lane) {
         S.X[i] = x ^ ((i == IT && g == GT) ? pl : add);                                     // the pivot column itself only loses its pivot bit
     }
     S.live &= ~pl;
-    const int ppu = __builtin_amdgcn_readfirstlane(pp);
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(S.oppv) : "s"(ppu), "n"(T));          // lane t of oppv: pivot row of column t
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(S.oppv) : "s"(pp), "n"(T));           // lane t of oppv: pivot row of column t
     S.pivmask |= 1u << T;
     S.nops++;
 }
 
+// phase 3 for one row per lane: U[q] ^= XOR_{k : bit pp_k of U[q]} C_k.  The 16 tested dwords are read back to back; a tested bit becomes a
+// 64-lane mask (one compare writing a scalar pair), so "nobody in the wave" is a scalar test, a visited operation runs under its mask, and
+// the row is read and written once however many masks it takes.  All 64 lanes of a wave call this together.
+template <bool W16>
+__device__ __forceinline__ void gj_rows_apply(unsigned long long *U, const unsigned long long *R, int qq, int mw, uint32_t valid, int ppv, int lane, unsigned long long &c_gather) {
+    const long long tg = OSD_CLOCK();
+    // byte offset of the row; rows of 16 words are 128-byte aligned, so the pair swizzle and a dword offset both fold in by XOR
+    const uint32_t rb = W16 ? (((uint32_t)qq << 7) ^ ((uint32_t)((qq >> 3) & 14) << 3)) : (uint32_t)qq * (uint32_t)mw * 8u;
+    const unsigned char *Ub = reinterpret_cast<const unsigned char *>(U);
+    uint32_t Pw[16];
+    int pk[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pk[k] = __builtin_amdgcn_readlane(ppv, k);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t off = (uint32_t)(pk[k] >> 5) << 2;                                   // the dword holding row pp_k
+        Pw[k] = *reinterpret_cast<const uint32_t *>(Ub + (W16 ? (rb ^ off) : (rb + off)));
+    }
+    ulonglong2 acc[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) acc[w] = make_ulonglong2(0ull, 0ull);
+    unsigned long long touched = 0ull;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        unsigned long long mk[8], any = 0ull;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = 8 * half + j;
+            mk[j] = ((valid >> k) & 1u) ? __ballot(((Pw[k] >> (pk[k] & 31)) & 1u) != 0u) : 0ull;
+            any |= mk[j];
+        }
+        if (half == 1) c_gather += OSD_CLOCK() - tg;
+        if (any == 0ull) continue;
+        touched |= any;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (mk[j] == 0ull) continue;                                                    // nobody in the wave: scalar skip
+            const int k = 8 * half + j;
+            if ((mk[j] >> lane) & 1ull) {
+                if (W16) {
+                    const ulonglong2 *mk2 = reinterpret_cast<const ulonglong2 *>(R + k * 16);
+                    ulonglong2 k2[8];
+#pragma unroll
+                    for (int w = 0; w < 8; w++) k2[w] = mk2[w];
+#pragma unroll
+                    for (int w = 0; w < 8; w++) { acc[w].x ^= k2[w].x; acc[w].y ^= k2[w].y; }
+                } else {
+                    unsigned long long *rowbase = U + qq * mw;
+                    for (int w = 0; w < mw; w++) rowbase[w] ^= R[k * mw + w];
+                }
+            }
+        }
+    }
+    if (W16 && touched != 0ull && ((touched >> lane) & 1ull)) {
+        ulonglong2 *Uq = reinterpret_cast<ulonglong2 *>(U + qq * 16);
+        const int sz = (qq >> 4) & 7;
+        ulonglong2 u[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) u[w] = Uq[w ^ sz];
+#pragma unroll
+        for (int w = 0; w < 8; w++) { u[w].x ^= acc[w].x; u[w].y ^= acc[w].y; }
+#pragma unroll
+        for (int w = 0; w < 8; w++) Uq[w ^ sz] = u[w];
+    }
+}
+
+template <bool W16>      // rows of 16 words (897 <= m <= 1024, 1024 threads): the circuit-level matrices
 __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
     extern __shared__ unsigned char lds[];
     const int m = P.m, n = P.n, mw = P.mw, K = P.K, cd = P.cdeg, tid = threadIdx.x, T = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: branches on it are wave-uniform for the compiler too
     unsigned long long *U = reinterpret_cast<unsigned long long *>(lds);
     uint16_t *sidx = reinterpret_cast<uint16_t *>(lds + P.offIdx);         // [K] columns of the current chunk
     uint8_t *alive = reinterpret_cast<uint8_t *>(lds + P.offAlive);        // [K]
@@ -101,7 +179,7 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
     int *s_item = opp + kGjBlock;
     uint16_t *ordw = P.ordws + (size_t)blockIdx.x * n;
     const int brow = m + 1;
-    auto uix = [&](int q, int w) -> int { return uswz(q, w, mw); };
+    auto uix = [&](int q, int w) -> int { return W16 ? q * 16 + (w ^ ((q >> 3) & 14)) : q * mw + w; };      // (uswz, osd_common.h)
 
     const int total = *P.count;
     const ClkStamp clk0 = clk_begin(P.clk);
@@ -131,12 +209,24 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
         for (int r = tid; r < m; r += T) {
             U[uix(r, r >> 6)] = 1ull << (r & 63);
             int sy = synd[r] & 1;
-            for (int e = P.indptr[r]; e < P.indptr[r + 1]; e++) sy ^= hard[P.indices[e]] & 1;
+            if (P.ell_col) {                                                 // slot-major row view: eight column loads, then eight loads of hard, in flight
+                const int deg = P.deg_of_row[r];
+                for (int k0 = 0; k0 < deg; k0 += 8) {
+                    int cj[8];
+#pragma unroll
+                    for (int j2 = 0; j2 < 8; j2++) cj[j2] = (k0 + j2 < deg) ? (int)P.ell_col[(size_t)(k0 + j2) * m + r] : -1;
+#pragma unroll
+                    for (int j2 = 0; j2 < 8; j2++) sy ^= (cj[j2] >= 0) ? (hard[cj[j2]] & 1) : 0;
+                }
+            } else {
+                for (int e = P.indptr[r]; e < P.indptr[r + 1]; e++) sy ^= hard[P.indices[e]] & 1;
+            }
             if (sy) atomicOr(&U[uix(brow, r >> 6)], 1ull << (r & 63));
         }
         __syncthreads();
         int row = 0, par = 0;                                                // pivots so far; parity of the block count (usedw buffer in force)
-        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0;
+        unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0, c_own = 0, c_col = 0, c_gat = 0, c_p3own = 0;
+        (void)c_own; (void)c_col; (void)c_gat; (void)c_p3own;
         const long long t_sorted = OSD_CLOCK();
         bool finished = (P.rankH == 0);
         for (int base = 0; base < n && !finished; base += K) {
@@ -154,37 +244,45 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                 colrows[t] = (k < P.colptr[j + 1]) ? (uint16_t)P.rowidx[k] : (uint16_t)m;          // row m of U is all zero
             }
             __syncthreads();
-            // drops every still-alive column of the chunk from c0 on that lies in the span of the pivots so far (one thread per column);
-            // `used` must be the buffer that matches the state of U
-            auto kill_pass = [&](int c0, int t0, int tstride, const unsigned long long *used) {
-                for (int c2 = c0 + t0; c2 < L; c2 += tstride) {
-                    if (!alive[c2]) continue;
+            // drops every still-alive column in [c0, c1) of the chunk that lies in the span of the pivots so far.  Four lanes (a quad) per column,
+            // lane g of the quad taking the words g, g + 4, ..: the threads t0 = 0 .. tcount - 1 (tcount a multiple of 4, whole quads) take part.
+            // `used` must be the buffer that matches the state of U.
+            auto kill_pass = [&](int c0, int c1, int t0, int tcount, const unsigned long long *used) {
+                const int g4 = t0 & 3;
+                for (int c2 = c0 + (t0 >> 2); c2 < c1; c2 += tcount >> 2) {
+                    if (!alive[c2]) continue;                                // (the same for the four lanes of the quad)
                     const uint16_t *cr2 = colrows + c2 * cd;
                     int rr[8];
 #pragma unroll
                     for (int d = 0; d < 8; d++) rr[d] = (d < cd) ? (int)cr2[d] : m;
                     unsigned long long any = 0ull;
-                    for (int w = 0; w < mw; w++) {
+                    for (int w = g4; w < mw; w += 4) {
+                        const unsigned long long lv = ~used[w];
+                        if (lv == 0ull) continue;                            // every row of this word has pivoted
                         unsigned long long xs[8];
 #pragma unroll
-                        for (int d = 0; d < 8; d++) xs[d] = U[uix(rr[d], w)];
+                        for (int d = 0; d < 8; d++) xs[d] = (d < cd) ? U[uix(rr[d], w)] : 0ull;
                         unsigned long long x = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
                         for (int d = 8; d < cd; d++) x ^= U[uix(cr2[d], w)];
-                        any |= x & ~used[w];
+                        any |= x & lv;
                     }
-                    if (!any) alive[c2] = 0;
+                    int f = (any != 0ull) ? 1 : 0;                           // OR over the quad
+                    f |= __builtin_amdgcn_update_dpp(0, f, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+                    f |= __builtin_amdgcn_update_dpp(0, f, 0x4E, 0xF, 0xF, true);          // quad_perm [2,3,0,1]
+                    if (!f && g4 == 0) alive[c2] = 0;
                 }
             };
             bool kill_due = false;
             if (row > 0) {                                                   // a fresh chunk late in the sweep is mostly dependent columns
                 long long tk = OSD_CLOCK();
                 d_kills++;
-                kill_pass(0, tid, T, usedw + 16 * par);
+                kill_pass(0, L, tid, T, usedw + 16 * par);
                 __syncthreads();
                 c_kill += OSD_CLOCK() - tk;
             }
             while (true) {
-                if (tid < 64) {                                              // wave 0 collects the next alive columns of the chunk (ballot scan)
+                const long long tc = OSD_CLOCK();
+                if (wave == 0) {                                             // wave 0 collects the next alive columns of the chunk (ballot scan)
                     int c = blk[3], nbc = 0;
                     while (c < L && nbc < kGjBlock) {
                         const int cc = c + tid;
@@ -206,6 +304,7 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                 }
                 __syncthreads();
                 const int nb = blk[0];
+                c_col += OSD_CLOCK() - tc;
                 if (nb == 0) break;
                 d_blocks++; d_cols += nb;
                 long long tp = OSD_CLOCK();
@@ -228,8 +327,11 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                 // ---- phase 2: the block's pivots and composite masks, wave 0 on registers; the other waves run a due dependent-column test ----
                 const unsigned long long *used_now = usedw + 16 * par;
                 unsigned long long *used_next = usedw + 16 * (par ^ 1);
-                if (tid < 64) {
+                if (wave == 0) {
                     const int lane = tid, g = lane & 3, w = lane >> 2;
+#ifdef QLDPC_GJ_PRIO
+                    __builtin_amdgcn_s_setprio(3);
+#endif
                     GjBlock S;
 #pragma unroll
                     for (int i = 0; i < 4; i++) S.X[i] = (4 * i + g < nb && w < mw) ? R[(4 * i + g) * mw + w] : 0ull;
@@ -249,8 +351,26 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                     }
                     if (lane < nb && ((S.depmask >> lane) & 1u)) alive[bcol[lane]] = 0;
                     if (lane == 0) { blk[1] = (int)S.pivmask; blk[2] = (S.depmask != 0u) ? 1 : 0; }
+#ifdef QLDPC_GJ_PRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef QLDPC_OSD_TIMERS
+                    c_own += OSD_CLOCK() - tp;
+#endif
+#if defined(QLDPC_GJ_NOKILLDEFER)
+                }
+                if (kill_due) { __syncthreads(); kill_pass(blk[3], L, tid, T, used_now); }
+                if (false) {
+#elif defined(QLDPC_GJ_KILLSIMD)
+                } else if (kill_due && (wave & 3) != 0) {                    // (waves 4, 8, 12 share wave 0's SIMD)
+                    kill_pass(blk[3], L, (wave - 1 - (wave >> 2)) * 64 + (tid & 63), (T >> 6) * 48, used_now);
+#else
                 } else if (kill_due) {
-                    kill_pass(blk[3], tid - 64, T - 64, used_now);
+                    kill_pass(blk[3], min(L, blk[3] + kGjKillWindow), tid - 64, T - 64, used_now);   // (what the next blocks will take)
+#endif
+#ifdef QLDPC_OSD_TIMERS
+                    c_own += OSD_CLOCK() - tp;
+#endif
                 }
                 if (kill_due) { d_kills++; kill_due = false; }
                 __syncthreads();
@@ -262,59 +382,15 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                 if (nops > 0) {
                     int ppv = opp[tid & 15];                                 // column k's pivot row sits in lane k of every 16
                     asm volatile("" : "+v"(ppv));
-                    const bool strided = (mw == 16);
                     for (int qb = 0; qb < m + 2; qb += T) {
-                        const int q = strided ? qb + ((tid & 63) << 4) + (((tid >> 6) + tid) & 15) : qb + tid;
+                        const int q = W16 ? qb + ((tid & 63) << 4) + (((tid >> 6) + tid) & 15) : qb + tid;
                         const bool act = (q < m + 2) && (q != m);
-                        const int qq = act ? q : m;
-                        unsigned long long *rowbase = U + qq * mw;
-                        const int swz = (mw == 16) ? ((qq >> 3) & 14) : 0;
-                        const uint32_t *row32 = reinterpret_cast<const uint32_t *>(rowbase);
-                        uint32_t Pw[16], s0 = 0u;
-#pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            const int pk = ((valid >> k) & 1u) ? __builtin_amdgcn_readlane(ppv, k) : 0;
-                            Pw[k] = row32[2 * ((pk >> 6) ^ swz) + ((pk >> 5) & 1)];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            const int pk = __builtin_amdgcn_readlane(ppv, k);
-                            s0 |= ((Pw[k] >> (pk & 31)) & 1u) << k;
-                        }
-                        s0 &= valid;
-                        if (!act) s0 = 0u;
-                        uint32_t x = s0;                                     // OR over the wave
-                        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
-                        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);        // quad_perm [2,3,0,1]
-                        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);       // row_half_mirror
-                        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);       // row_mirror
-                        uint32_t wtb = (uint32_t)__builtin_amdgcn_readlane((int)x, 0) | (uint32_t)__builtin_amdgcn_readlane((int)x, 16) |
-                                       (uint32_t)__builtin_amdgcn_readlane((int)x, 32) | (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
-                        while (wtb != 0u) {
-                            const int k = __builtin_ctz(wtb);
-                            wtb &= wtb - 1u;
-                            const unsigned long long *mk = R + k * mw;
-                            if ((s0 >> k) & 1u) {
-                                if (mw == 16) {                              // all reads in flight before the first XOR
-                                    ulonglong2 u[8], k2[8];
-                                    ulonglong2 *Uq = reinterpret_cast<ulonglong2 *>(rowbase);
-                                    const ulonglong2 *mk2 = reinterpret_cast<const ulonglong2 *>(mk);
-                                    const int sz = swz >> 1;
-#pragma unroll
-                                    for (int w = 0; w < 8; w++) u[w] = Uq[w ^ sz];
-#pragma unroll
-                                    for (int w = 0; w < 8; w++) k2[w] = mk2[w];
-#pragma unroll
-                                    for (int w = 0; w < 8; w++) { u[w].x ^= k2[w].x; u[w].y ^= k2[w].y; }
-#pragma unroll
-                                    for (int w = 0; w < 8; w++) Uq[w ^ sz] = u[w];
-                                } else {
-                                    for (int w = 0; w < mw; w++) rowbase[w] ^= mk[w];
-                                }
-                            }
-                        }
+                        gj_rows_apply<W16>(U, R, act ? q : m, mw, valid, ppv, tid & 63, c_gat);      // idle lanes look at the all-zero row: none of their bits is set
                     }
                 }
+#ifdef QLDPC_OSD_TIMERS
+                c_p3own += OSD_CLOCK() - tp;
+#endif
                 row += nops;
                 __syncthreads();
                 c_p3 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
@@ -329,6 +405,12 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
             atomicAdd(&P.dbg[8], (unsigned long long)(t_sorted - t_start)); atomicAdd(&P.dbg[9], c_p1); atomicAdd(&P.dbg[10], c_p2); atomicAdd(&P.dbg[11], c_p3);
             atomicAdd(&P.dbg[12], c_kill);
         }
+#ifdef QLDPC_OSD_TIMERS
+        if (P.dbg && tid == 0) { atomicAdd(&P.dbg[13], c_own); atomicAdd(&P.dbg[15], c_col); }      // [13] wave 0's pivot chains, [14] the dependent-column
+        if (P.dbg && tid == 64) atomicAdd(&P.dbg[14], c_own);
+        if (P.dbg && tid == 0) atomicAdd(&P.dbg[7], c_gat);                                          // [7] wave 0: phase 3 up to the tested bits
+        if (P.dbg && (tid & 127) == 0) atomicAdd(&P.dbg[24 + (tid >> 7)], c_p3own);                  // [24..31] phase 3 of waves 0, 2, .. 14 without the barrier                                        // tests of wave 1 beside them, [15] block collection
+#endif
         // ---- back-fill (osd.py:19-25): e[pivot col] = reduced rhs at the pivot row; solution = (hard + e) % 2 ----
         __syncthreads();
         if (sol != hard) for (int j = tid; j < n; j += T) sol[j] = hard[j];
@@ -379,6 +461,7 @@ int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d
     if ((rc = g->ws_queue.ensure(16)) != QLDPC_OK) return rc;
     P.ordws = g->ws_misc.as<uint16_t>();
     P.colptr = g->d_colptr; P.rowidx = g->d_rowidx; P.indptr = g->d_indptr; P.indices = g->d_indices;
+    P.ell_col = (g->d_ell_col && g->d_deg_of_row) ? g->d_ell_col : nullptr; P.deg_of_row = g->d_deg_of_row;
     P.list = d_list; P.count = d_count; P.synd = d_synd; P.llr = d_llr; P.hard = d_hard; P.ordering = d_ordering; P.solution = d_solution;
     P.clk = g->clk_probe;
     P.dbg = osd_timer_buffer();
@@ -387,8 +470,10 @@ int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d
     QLDPC_HIP_TRY(hipMemsetAsync(P.queue, 0, 4, stream));
     QLDPC_HIP_TRY(hipMemsetAsync(P.redo_count, 0, 4, stream));
     const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m + 2, 256), 64));
-    if ((rc = ensure_max_lds(g->device, reinterpret_cast<const void *>(osd0_gj_kernel), 160 * 1024)) != QLDPC_OK) return rc;
-    hipLaunchKernelGGL(osd0_gj_kernel, dim3(grid), dim3(block), lds, stream, P);
+    if ((rc = ensure_max_lds(g->device, reinterpret_cast<const void *>(osd0_gj_kernel<true>), 160 * 1024)) != QLDPC_OK) return rc;
+    if ((rc = ensure_max_lds(g->device, reinterpret_cast<const void *>(osd0_gj_kernel<false>), 160 * 1024)) != QLDPC_OK) return rc;
+    if (P.mw == 16 && block == 1024) hipLaunchKernelGGL(osd0_gj_kernel<true>, dim3(grid), dim3(block), lds, stream, P);
+    else hipLaunchKernelGGL(osd0_gj_kernel<false>, dim3(grid), dim3(block), lds, stream, P);
     QLDPC_HIP_TRY(hipGetLastError());
     handled = true;
     return QLDPC_OK;

@@ -26,8 +26,11 @@ ap.add_argument("--reps", type=int, default=1)
 ap.add_argument("--counts-out", default="", help="with --timers: write the OSD-0 workload counts per shot (pivots, columns, touched row updates) as JSON")
 ap.add_argument("--cpu-trials", type=int, default=0, help="also time the CPU checker (C port of the reference loop, all host threads) on this many trials")
 ap.add_argument("--timers", action="store_true", help="load libqldpc_hip_timers.so (make -C csrc timers): in-kernel phase counters")
+ap.add_argument("--build", default="", help="a library file name in csrc/ (A/B builds made by tools/ab_build.sh)")
 a = ap.parse_args()
-if a.timers:
+if a.build:
+    _lib.select_build(a.build)
+elif a.timers:
     _lib.select_build("timers")
 d = load_circuit_matrices(a.tag)
 c = load_code(str(d["code"]))
@@ -78,7 +81,7 @@ for rep in range(a.reps):
         if h[0]:
             print(f"  [osd timers] shots={h[0]:.0f} chunks/shot={h[1] / h[0]:.2f} cols/shot={h[2] / h[0]:.1f} pivots/shot={h[3] / h[0]:.1f} kills/shot={h[5] / h[0]:.1f} "
                   f"blocks/shot={h[6] / h[0]:.1f} kcycles/shot={h[4] / h[0] / 1e3:.1f} (sort {h[8] / h[0] / 1e3:.0f} p1 {h[9] / h[0] / 1e3:.0f} p2 {h[10] / h[0] / 1e3:.0f} "
-                  f"p3 {h[11] / h[0] / 1e3:.0f} kill {h[12] / h[0] / 1e3:.0f} backsub {h[13] / h[0] / 1e3:.0f}; extra counters per shot [7] {h[7] / h[0]:.1f} [14] {h[14] / h[0]:.1f} [15] {h[15] / h[0]:.1f})", flush=True)
+                  f"p3 {h[11] / h[0] / 1e3:.0f} kill {h[12] / h[0] / 1e3:.0f} backsub {h[13] / h[0] / 1e3:.0f}; extra counters per shot [7] {h[7] / h[0]:.1f} [14] {h[14] / h[0]:.1f} [15] {h[15] / h[0]:.1f} [24..31] " + " ".join(f"{x / h[0] / 1e3:.0f}" for x in h[24:32]) + ")", flush=True)
             if a.counts_out:
                 import json
                 mz = int(d["HdecZ_shape"][0])
