@@ -49,6 +49,11 @@ constexpr int kGjBlock = 16;
 #ifndef QLDPC_GJ_KILLWINDOW
 #define QLDPC_GJ_KILLWINDOW 240
 #endif
+#ifndef QLDPC_GJ_KILLEVERY
+#define QLDPC_GJ_KILLEVERY 2
+#endif
+constexpr int kGjKillEvery = QLDPC_GJ_KILLEVERY;        // a block that met dependent columns asks for a test on every that-many-th block (the test sits on the
+                                                        // critical path of its block, a dependent column in a chain costs less than a pivot)
 constexpr int kGjKillWindow = QLDPC_GJ_KILLWINDOW;      // columns behind a block that its dependent-column test covers
 
 struct GjBlock {
@@ -172,11 +177,13 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
     uint16_t *colrows = reinterpret_cast<uint16_t *>(lds + P.offRows);     // [K][cd] supports
     uint16_t *pvcol = reinterpret_cast<uint16_t *>(lds + P.offPc);         // [m] column of pivot t
     uint16_t *pvrow = reinterpret_cast<uint16_t *>(lds + P.offPr);         // [m] row of pivot t
-    unsigned long long *R = reinterpret_cast<unsigned long long *>(lds + P.offR);       // [16][mw] reduced columns -> composite masks
+    unsigned long long *R = reinterpret_cast<unsigned long long *>(lds + P.offR);       // [16][mw] reduced columns of the block in flight
+    unsigned long long *Cb = R + kGjBlock * mw;                                          // [2][16][mw] composite masks, by block parity
     unsigned long long *usedw = reinterpret_cast<unsigned long long *>(lds + P.offUsed); // [2][16] rows that have pivoted, by block parity
     int *blk = reinterpret_cast<int *>(lds + P.offBlk);                    // [0] nb, [1] pivot mask, [2] anydep, [3] next c; [4..] cols[16], opp[16]
-    int *bcol = blk + 4, *opp = bcol + kGjBlock;
-    int *s_item = opp + kGjBlock;
+    int *bcolb = blk + 4, *oppb = bcolb + 2 * kGjBlock;                   // bcolb [2][16]: the block's columns (positions in the chunk), double-buffered; oppb [2][16]: pivot rows, by block parity
+    uint32_t *selb = reinterpret_cast<uint32_t *>(oppb + 2 * kGjBlock);   // [16] pending operations a column of the block still needs
+    int *s_item = reinterpret_cast<int *>(selb + kGjBlock), *sbar = s_item + 1, *nbb = s_item + 2;      // sbar: arrivals at the barrier of the waves 1 .. 15; nbb [2]: block sizes
     uint16_t *ordw = P.ordws + (size_t)blockIdx.x * n;
     const int brow = m + 1;
     auto uix = [&](int q, int w) -> int { return W16 ? q * 16 + (w ^ ((q >> 3) & 14)) : q * mw + w; };      // (uswz, osd_common.h)
@@ -205,6 +212,8 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
             const int w = tid & 15;
             usedw[tid] = (w >= mw) ? ~0ull : ((w == mw - 1 && (m & 63)) ? (~0ull << (m & 63)) : 0ull);
         }
+        if (tid == 0) *sbar = 0;
+        if (tid < 16) selb[tid] = 0u;
         __syncthreads();
         for (int r = tid; r < m; r += T) {
             U[uix(r, r >> 6)] = 1ull << (r & 63);
@@ -224,7 +233,10 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
             if (sy) atomicOr(&U[uix(brow, r >> 6)], 1ull << (r & 63));
         }
         __syncthreads();
-        int row = 0, par = 0;                                                // pivots so far; parity of the block count (usedw buffer in force)
+        int row = 0, cb = 0, ub = 0, bi = 0;                                         // pivots so far; buffer of the next block's masks / of the used rows in force
+        uint32_t pend = 0u;                                                  // pivot mask of the block whose operations U has not seen yet
+        bool kill_due = false;
+        int sbar_target = 0;                                                 // (the partial barrier counts up for the whole shot)
         unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0, c_own = 0, c_col = 0, c_gat = 0, c_p3own = 0;
         (void)c_own; (void)c_col; (void)c_gat; (void)c_p3own;
         const long long t_sorted = OSD_CLOCK();
@@ -272,45 +284,57 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                     if (!f && g4 == 0) alive[c2] = 0;
                 }
             };
-            bool kill_due = false;
+            // U lags the pivots by the pending block: the set of used rows that matches it is the one the pending block's chain started from
             if (row > 0) {                                                   // a fresh chunk late in the sweep is mostly dependent columns
                 long long tk = OSD_CLOCK();
                 d_kills++;
-                kill_pass(0, L, tid, T, usedw + 16 * par);
+                kill_pass(0, L, tid, T, usedw + 16 * (pend ? (ub ^ 1) : ub));
                 __syncthreads();
                 c_kill += OSD_CLOCK() - tk;
             }
-            while (true) {
-                const long long tc = OSD_CLOCK();
-                if (wave == 0) {                                             // wave 0 collects the next alive columns of the chunk (ballot scan)
-                    int c = blk[3], nbc = 0;
-                    while (c < L && nbc < kGjBlock) {
-                        const int cc = c + tid;
-                        const bool al = (cc < L) && alive[cc];
-                        const unsigned long long bal = __ballot(al);
-                        const int before = __builtin_popcountll(bal & ((1ull << tid) - 1ull));
-                        if (al && nbc + before < kGjBlock) bcol[nbc + before] = cc;
-                        const int got = __builtin_popcountll(bal);
-                        if (nbc + got >= kGjBlock) {                          // stop right behind the column that filled the block
-                            int need = kGjBlock - nbc;
-                            unsigned long long bb = bal;
-                            int lastpos = 0;
-                            while (need-- > 0) { lastpos = __builtin_ctzll(bb); bb &= bb - 1; }
-                            c += lastpos + 1; nbc = kGjBlock;
-                        } else { nbc += got; c += 64; }
-                    }
-                    if (c > L) c = L;
-                    if (tid == 0) { blk[0] = nbc; blk[1] = 0; blk[2] = 0; blk[3] = c; }
+            // one wave gathers the next (up to 16) alive columns of the chunk from blk[3] on into block buffer `to` (ballot scan)
+            auto collect_block = [&](int to) {
+                const int lane = tid & 63;
+                int *bc = bcolb + 16 * to;
+                int c = blk[3], nbc = 0;
+                while (c < L && nbc < kGjBlock) {
+                    const int cc = c + lane;
+                    const bool al = (cc < L) && alive[cc];
+                    const unsigned long long bal = __ballot(al);
+                    const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                    if (al && nbc + before < kGjBlock) bc[nbc + before] = cc;
+                    const int got = __builtin_popcountll(bal);
+                    if (nbc + got >= kGjBlock) {                              // stop right behind the column that filled the block
+                        int need = kGjBlock - nbc;
+                        unsigned long long bb = bal;
+                        int lastpos = 0;
+                        while (need-- > 0) { lastpos = __builtin_ctzll(bb); bb &= bb - 1; }
+                        c += lastpos + 1; nbc = kGjBlock;
+                    } else { nbc += got; c += 64; }
                 }
+                if (c > L) c = L;
+                if (lane == 0) { nbb[to] = nbc; blk[3] = c; }
+            };
+            {
+                const long long tc = OSD_CLOCK();
+                if (wave == 0) collect_block(bi);
                 __syncthreads();
-                const int nb = blk[0];
                 c_col += OSD_CLOCK() - tc;
+            }
+            while (true) {
+                const int nb = nbb[bi];
+                const int *bcol = bcolb + 16 * bi;
                 if (nb == 0) break;
                 d_blocks++; d_cols += nb;
                 long long tp = OSD_CLOCK();
-                // ---- phase 1: reduced columns R[t] = XOR of U rows ----
-                for (int x = tid; x < nb * mw; x += T) {
-                    const int t = x / mw, w = x - t * mw;
+                const int cprev = cb ^ 1;                                    // buffers of the pending block (operations known, U not yet updated)
+                // ---- (B) reduced columns from the LAGGING U, R[t] = XOR of U rows, plus which pending operations each still needs (bit pp_k of the
+                //      column: the pending block's transform on a column is r ^= XOR_{k : r[pp_k]} C_k, tested on the lagging r).  The waves without
+                //      a column run a due dependent-column test on the same consistent state. ----
+                int ppvPrev = oppb[16 * cprev + (tid & 15)];                 // pending column k's pivot row sits in lane k of every 16
+                asm volatile("" : "+v"(ppvPrev));
+                if (tid < nb * mw) {
+                    const int t = tid / mw, w = tid - t * mw;
                     const uint16_t *cr = colrows + bcol[t] * cd;
                     int rr[8];
                     unsigned long long xs[8];
@@ -321,83 +345,120 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                     unsigned long long acc = ((xs[0] ^ xs[1]) ^ (xs[2] ^ xs[3])) ^ ((xs[4] ^ xs[5]) ^ (xs[6] ^ xs[7]));
                     for (int d = 8; d < cd; d++) acc ^= U[uix(cr[d], w)];
                     R[t * mw + w] = acc;
+                    uint32_t mysel = 0u;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const int pk = __builtin_amdgcn_readlane(ppvPrev, k);
+                        mysel |= ((pk >> 6) == w && ((acc >> (pk & 63)) & 1ull)) ? (1u << k) : 0u;
+                    }
+                    mysel &= pend;
+                    if (mysel) atomicOr(&selb[t], mysel);
                 }
                 __syncthreads();
                 c_p1 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
-                // ---- phase 2: the block's pivots and composite masks, wave 0 on registers; the other waves run a due dependent-column test ----
-                const unsigned long long *used_now = usedw + 16 * par;
-                unsigned long long *used_next = usedw + 16 * (par ^ 1);
+                // ---- (C) wave 0: the pending operations applied to the block's columns, then the block's pivots and composite masks on
+                //      registers; the other waves: the pending block's row updates U[q] ^= XOR_{k : bit pp_k of U[q]} C_k (and b) ----
                 if (wave == 0) {
                     const int lane = tid, g = lane & 3, w = lane >> 2;
-#ifdef QLDPC_GJ_PRIO
-                    __builtin_amdgcn_s_setprio(3);
-#endif
+                    __builtin_amdgcn_s_setprio(3);                           // (three row-update waves share this SIMD)
                     GjBlock S;
 #pragma unroll
                     for (int i = 0; i < 4; i++) S.X[i] = (4 * i + g < nb && w < mw) ? R[(4 * i + g) * mw + w] : 0ull;
-                    S.live = ~used_now[w];
+                    if (pend) {
+                        uint32_t sl4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) sl4[i] = (4 * i + g < nb && w < mw) ? selb[4 * i + g] : 0u;
+                        if (lane < 16) selb[lane] = 0u;                      // (read above; refilled by the next block's column work)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            uint32_t sl = sl4[i];
+                            while (sl != 0u) {
+                                const int k = __builtin_ctz(sl);
+                                sl &= sl - 1u;
+                                S.X[i] ^= Cb[(16 * cprev + k) * mw + w];
+                            }
+                        }
+                    }
+                    S.live = ~usedw[16 * ub + w];
                     S.nops = 0; S.maxops = P.rankH - row; S.depmask = 0u; S.pivmask = 0u; S.oppv = 0;
 #define QLDPC_GSTEP(TT) if (TT < nb && S.nops < S.maxops) gj_pivot_step<TT>(S, lane);
                     QLDPC_GSTEP(0) QLDPC_GSTEP(1) QLDPC_GSTEP(2) QLDPC_GSTEP(3) QLDPC_GSTEP(4) QLDPC_GSTEP(5) QLDPC_GSTEP(6) QLDPC_GSTEP(7)
                     QLDPC_GSTEP(8) QLDPC_GSTEP(9) QLDPC_GSTEP(10) QLDPC_GSTEP(11) QLDPC_GSTEP(12) QLDPC_GSTEP(13) QLDPC_GSTEP(14) QLDPC_GSTEP(15)
 #undef QLDPC_GSTEP
 #pragma unroll
-                    for (int i = 0; i < 4; i++) if (4 * i + g < nb && w < mw) R[(4 * i + g) * mw + w] = S.X[i];
-                    if (g == 0) used_next[w] = ~S.live;
-                    if (lane < 16) opp[lane] = S.oppv;
+                    for (int i = 0; i < 4; i++) if (4 * i + g < nb && w < mw) Cb[(16 * cb + 4 * i + g) * mw + w] = S.X[i];
+                    if (g == 0) usedw[16 * (ub ^ 1) + w] = ~S.live;
+                    if (lane < 16) oppb[16 * cb + lane] = S.oppv;
                     if (lane < 16 && ((S.pivmask >> lane) & 1u)) {
                         const int t = row + __builtin_popcount(S.pivmask & ((1u << lane) - 1u));
                         pvcol[t] = sidx[bcol[lane]]; pvrow[t] = (uint16_t)S.oppv;
                     }
                     if (lane < nb && ((S.depmask >> lane) & 1u)) alive[bcol[lane]] = 0;
                     if (lane == 0) { blk[1] = (int)S.pivmask; blk[2] = (S.depmask != 0u) ? 1 : 0; }
-#ifdef QLDPC_GJ_PRIO
                     __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef QLDPC_OSD_TIMERS
                     c_own += OSD_CLOCK() - tp;
 #endif
-#if defined(QLDPC_GJ_NOKILLDEFER)
+                } else if (pend) {
+                    const int ppv = ppvPrev;
+                    const unsigned long long *Cp = Cb + 16 * cprev * mw;
+                    if (W16) {
+                        // rows go to threads as q = 16 * lane + (v + lane) % 16, v = 0 .. 15 (conflict-free 16-byte row accesses under the pair swizzle);
+                        // waves 1 .. 15 stand for v = 0 .. 14, wave 1 then takes v = 15
+                        for (int v = wave - 1; v < 16; v += 15) {
+                            const int q = ((tid & 63) << 4) + ((v + tid) & 15);
+                            const bool act = (q < m + 2) && (q != m);
+                            gj_rows_apply<W16>(U, Cp, act ? q : m, mw, pend, ppv, tid & 63, c_gat);
+                            if (wave != 1) break;
+                        }
+                    } else {
+                        for (int qb = 0; qb < m + 2; qb += T - 64) {
+                            const int q = qb + tid - 64;
+                            const bool act = (q < m + 2) && (q != m);
+                            gj_rows_apply<W16>(U, Cp, act ? q : m, mw, pend, ppv, tid & 63, c_gat);      // idle lanes look at the all-zero row
+                        }
+                    }
+#ifdef QLDPC_OSD_TIMERS
+                    c_p3own += OSD_CLOCK() - tp;
+#endif
                 }
-                if (kill_due) { __syncthreads(); kill_pass(blk[3], L, tid, T, used_now); }
-                if (false) {
-#elif defined(QLDPC_GJ_KILLSIMD)
-                } else if (kill_due && (wave & 3) != 0) {                    // (waves 4, 8, 12 share wave 0's SIMD)
-                    kill_pass(blk[3], L, (wave - 1 - (wave >> 2)) * 64 + (tid & 63), (T >> 6) * 48, used_now);
-#else
-                } else if (kill_due) {
-                    kill_pass(blk[3], min(L, blk[3] + kGjKillWindow), tid - 64, T - 64, used_now);   // (what the next blocks will take)
-#endif
-#ifdef QLDPC_OSD_TIMERS
-                    c_own += OSD_CLOCK() - tp;
-#endif
+                if (wave != 0 && kill_due) {
+                    // a due dependent-column test on what the next blocks will take, once every row update of the pending block has landed (a
+                    // barrier of the waves 1 .. 15 only: wave 0 is in its pivot chain).  U then matches the used rows the chain started from.
+                    if (pend) {
+                        if ((tid & 63) == 0) atomicAdd(sbar, 1);
+                        sbar_target += (T >> 6) - 1;
+                        for (int spin = 0; *reinterpret_cast<volatile int *>(sbar) < sbar_target && spin < (1 << 22); spin++) __builtin_amdgcn_s_sleep(2);   // (bounded: the waves are resident and always arrive)
+                    }
+                    kill_pass(blk[3], min(L, blk[3] + kGjKillWindow), tid - 64, T - 64, usedw + 16 * ub);
                 }
                 if (kill_due) { d_kills++; kill_due = false; }
-                __syncthreads();
-                const uint32_t valid = (uint32_t)blk[1];                     // columns of the block that pivoted
-                const int nops = __builtin_popcount(valid), anydep = blk[2];
-                par ^= 1;
-                c_p2 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
-                // ---- phase 3: U[q] ^= XOR_{k : bit pp_k of U[q]} C_k for every row q (and for b) ----
-                if (nops > 0) {
-                    int ppv = opp[tid & 15];                                 // column k's pivot row sits in lane k of every 16
-                    asm volatile("" : "+v"(ppv));
-                    for (int qb = 0; qb < m + 2; qb += T) {
-                        const int q = W16 ? qb + ((tid & 63) << 4) + (((tid >> 6) + tid) & 15) : qb + tid;
-                        const bool act = (q < m + 2) && (q != m);
-                        gj_rows_apply<W16>(U, R, act ? q : m, mw, valid, ppv, tid & 63, c_gat);      // idle lanes look at the all-zero row: none of their bits is set
-                    }
-                }
-#ifdef QLDPC_OSD_TIMERS
-                c_p3own += OSD_CLOCK() - tp;
-#endif
-                row += nops;
-                __syncthreads();
-                c_p3 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
+                if (wave == 1) collect_block(bi ^ 1);                        // the next block's columns (a test still in flight in another wave may
+                __syncthreads();                                             // drop one of them a moment later: the chain then finds it dependent)
+                bi ^= 1;
+                pend = (uint32_t)blk[1];                                     // columns of the block that pivoted: its operations are pending now
+                const int anydep = blk[2];
+                row += __builtin_popcount(pend);
+                cb ^= 1; ub ^= 1;
+                c_p2 += OSD_CLOCK() - tp;
                 if (row >= P.rankH || row >= m) { finished = true; break; }
-                if (anydep) kill_due = true;                                 // done by the idle waves beside the next block's pivot chain
+                if (anydep && (d_blocks % kGjKillEvery) == 0) kill_due = true;      // done behind the next block's row updates
             }
             __syncthreads();      // nobody may refill alive[]/sidx[] while others still use them
+        }
+        if (pend) {                                                          // the last block's row updates, all waves
+            const long long tp = OSD_CLOCK();
+            const int cprev = cb ^ 1;
+            int ppv = oppb[16 * cprev + (tid & 15)];
+            asm volatile("" : "+v"(ppv));
+            for (int qb = 0; qb < m + 2; qb += T) {
+                const int q = W16 ? qb + ((tid & 63) << 4) + (((tid >> 6) + tid) & 15) : qb + tid;
+                const bool act = (q < m + 2) && (q != m);
+                gj_rows_apply<W16>(U, Cb + 16 * cprev * mw, act ? q : m, mw, pend, ppv, tid & 63, c_gat);
+            }
+            pend = 0u;
+            __syncthreads();
+            c_p3 += OSD_CLOCK() - tp;
         }
         if (P.dbg && tid == 0) {
             atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)row);
@@ -415,7 +476,7 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
         __syncthreads();
         if (sol != hard) for (int j = tid; j < n; j += T) sol[j] = hard[j];
         if (tid == 0) {                                                      // b outside the column space: a one of the reduced b in an unused row
-            const unsigned long long *used = usedw + 16 * par;
+            const unsigned long long *used = usedw + 16 * ub;
             unsigned long long bad = 0ull;
             for (int w = 0; w < mw; w++) bad |= U[uix(brow, w)] & ~used[w];
             if (bad) P.redo_list[atomicAdd(P.redo_count, 1)] = (int32_t)shot;
@@ -447,9 +508,9 @@ int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d
     P.offRows = (int)off; off += (size_t)round_up((int64_t)P.K * P.cdeg * 2, 8);
     P.offPc = (int)off; off += round_up((int64_t)g->m * 2, 8);
     P.offPr = (int)off; off += round_up((int64_t)g->m * 2, 8);
-    P.offR = (int)off; off += (size_t)kGjBlock * P.mw * 8;
+    P.offR = (int)off; off += (size_t)3 * kGjBlock * P.mw * 8;
     P.offUsed = (int)off; off += 32 * 8;
-    P.offBlk = (int)off; off += (4 + 3 * kGjBlock + 4) * 4;
+    P.offBlk = (int)off; off += (4 + 5 * kGjBlock + 8) * 4;
     const size_t lds = off + 16;
     if (lds > 160 * 1024) return QLDPC_OK;
     if (g->gf2_rank < 0) g->gf2_rank = host_gf2_rank(g);      // callers hold g->mu
