@@ -100,69 +100,67 @@ __device__ __forceinline__ void gj_pivot_step(GjBlock &S, int lane) {
     S.nops++;
 }
 
-// phase 3 for one row per lane: U[q] ^= XOR_{k : bit pp_k of U[q]} C_k.  The 16 tested dwords are read back to back; a tested bit becomes a
-// 64-lane mask (one compare writing a scalar pair), so "nobody in the wave" is a scalar test, a visited operation runs under its mask, and
-// the row is read and written once however many masks it takes.  All 64 lanes of a wave call this together.
+// phase 3 for one row per lane: U[q] ^= XOR_{k : bit pp_k of U[q]} C_k.  All 64 lanes of a wave call this together.
+// Rows of 16 words: the lane reads its whole row (eight 16-byte reads, conflict-free under the pair swizzle; sixteen 4-byte gathers of the tested
+// dwords, every lane another row, are 8-way bank conflicts each), takes the tested dwords out of the registers with a wave-uniform index, and a
+// tested bit becomes a 64-lane mask (one compare writing a scalar pair): "nobody in the wave" is a scalar test, a visited operation runs
+// under its mask, and a touched row is written back once.
+typedef uint32_t gj_row32 __attribute__((ext_vector_type(32)));
 template <bool W16>
 __device__ __forceinline__ void gj_rows_apply(unsigned long long *U, const unsigned long long *R, int qq, int mw, uint32_t valid, int ppv, int lane, unsigned long long &c_gather) {
     const long long tg = OSD_CLOCK();
-    // byte offset of the row; rows of 16 words are 128-byte aligned, so the pair swizzle and a dword offset both fold in by XOR
-    const uint32_t rb = W16 ? (((uint32_t)qq << 7) ^ ((uint32_t)((qq >> 3) & 14) << 3)) : (uint32_t)qq * (uint32_t)mw * 8u;
-    const unsigned char *Ub = reinterpret_cast<const unsigned char *>(U);
-    uint32_t Pw[16];
     int pk[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) pk[k] = __builtin_amdgcn_readlane(ppv, k);
+    if (W16) {
+        uint4 *Uq = reinterpret_cast<uint4 *>(U + qq * 16);
+        const int sz = (qq >> 4) & 7;
+        gj_row32 row;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t off = (uint32_t)(pk[k] >> 5) << 2;                                   // the dword holding row pp_k
-        Pw[k] = *reinterpret_cast<const uint32_t *>(Ub + (W16 ? (rb ^ off) : (rb + off)));
-    }
-    ulonglong2 acc[8];
-#pragma unroll
-    for (int w = 0; w < 8; w++) acc[w] = make_ulonglong2(0ull, 0ull);
-    unsigned long long touched = 0ull;
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        unsigned long long mk[8], any = 0ull;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = 8 * half + j;
-            mk[j] = ((valid >> k) & 1u) ? __ballot(((Pw[k] >> (pk[k] & 31)) & 1u) != 0u) : 0ull;
-            any |= mk[j];
+        for (int w = 0; w < 8; w++) {                                                       // logical order in the registers
+            const uint4 t = Uq[w ^ sz];
+            row[4 * w] = t.x; row[4 * w + 1] = t.y; row[4 * w + 2] = t.z; row[4 * w + 3] = t.w;
         }
-        if (half == 1) c_gather += OSD_CLOCK() - tg;
-        if (any == 0ull) continue;
-        touched |= any;
+        unsigned long long mk[16], touched = 0ull;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (mk[j] == 0ull) continue;                                                    // nobody in the wave: scalar skip
-            const int k = 8 * half + j;
-            if ((mk[j] >> lane) & 1ull) {
-                if (W16) {
-                    const ulonglong2 *mk2 = reinterpret_cast<const ulonglong2 *>(R + k * 16);
-                    ulonglong2 k2[8];
+        for (int k = 0; k < 16; k++) {
+            const uint32_t dw = row[(pk[k] >> 5) & 31];                                     // (wave-uniform register index)
+            mk[k] = ((valid >> k) & 1u) ? __ballot(((dw >> (pk[k] & 31)) & 1u) != 0u) : 0ull;
+            touched |= mk[k];
+        }
+        c_gather += OSD_CLOCK() - tg;
+        if (touched == 0ull) return;
 #pragma unroll
-                    for (int w = 0; w < 8; w++) k2[w] = mk2[w];
+        for (int k = 0; k < 16; k++) {
+            if (mk[k] == 0ull) continue;                                                    // nobody in the wave: scalar skip
+            if ((mk[k] >> lane) & 1ull) {
+                const uint4 *mk4 = reinterpret_cast<const uint4 *>(R + k * 16);
+                uint4 k4[8];
 #pragma unroll
-                    for (int w = 0; w < 8; w++) { acc[w].x ^= k2[w].x; acc[w].y ^= k2[w].y; }
-                } else {
-                    unsigned long long *rowbase = U + qq * mw;
-                    for (int w = 0; w < mw; w++) rowbase[w] ^= R[k * mw + w];
-                }
+                for (int w = 0; w < 8; w++) k4[w] = mk4[w];
+#pragma unroll
+                for (int w = 0; w < 8; w++) { row[4 * w] ^= k4[w].x; row[4 * w + 1] ^= k4[w].y; row[4 * w + 2] ^= k4[w].z; row[4 * w + 3] ^= k4[w].w; }
             }
         }
-    }
-    if (W16 && touched != 0ull && ((touched >> lane) & 1ull)) {
-        ulonglong2 *Uq = reinterpret_cast<ulonglong2 *>(U + qq * 16);
-        const int sz = (qq >> 4) & 7;
-        ulonglong2 u[8];
+        if ((touched >> lane) & 1ull) {
 #pragma unroll
-        for (int w = 0; w < 8; w++) u[w] = Uq[w ^ sz];
+            for (int w = 0; w < 8; w++) Uq[w ^ sz] = make_uint4(row[4 * w], row[4 * w + 1], row[4 * w + 2], row[4 * w + 3]);
+        }
+    } else {
+        const uint32_t *row32 = reinterpret_cast<const uint32_t *>(U + qq * mw);
+        uint32_t Pw[16];
 #pragma unroll
-        for (int w = 0; w < 8; w++) { u[w].x ^= acc[w].x; u[w].y ^= acc[w].y; }
+        for (int k = 0; k < 16; k++) Pw[k] = row32[pk[k] >> 5];
+        unsigned long long mk[16];
 #pragma unroll
-        for (int w = 0; w < 8; w++) Uq[w ^ sz] = u[w];
+        for (int k = 0; k < 16; k++) mk[k] = ((valid >> k) & 1u) ? __ballot(((Pw[k] >> (pk[k] & 31)) & 1u) != 0u) : 0ull;
+        c_gather += OSD_CLOCK() - tg;
+        unsigned long long *rowbase = U + qq * mw;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (mk[k] == 0ull) continue;
+            if ((mk[k] >> lane) & 1ull) for (int w = 0; w < mw; w++) rowbase[w] ^= R[k * mw + w];
+        }
     }
 }
 
