@@ -431,8 +431,9 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                     kill_pass(blk[3], min(L, blk[3] + kGjKillWindow), tid - 64, T - 64, usedw + 16 * ub);
                 }
                 if (kill_due) { d_kills++; kill_due = false; }
-                if (wave == 1) collect_block(bi ^ 1);                        // the next block's columns (a test still in flight in another wave may
-                __syncthreads();                                             // drop one of them a moment later: the chain then finds it dependent)
+                if (wave == 1) collect_block(bi ^ 1);                        // the next block's columns, behind the test (collecting before it, while wave 1
+                                                                             // waits for the later waves' rows, lets 7 % more dependent columns into the blocks)
+                __syncthreads();
                 bi ^= 1;
                 pend = (uint32_t)blk[1];                                     // columns of the block that pivoted: its operations are pending now
                 const int anydep = blk[2];
