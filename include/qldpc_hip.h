@@ -107,6 +107,13 @@ int qldpc_device_count(void);
  *   "mc_tail_overlap"     read at plan creation: 1 (default) = whole batches on the plan's own streams so that the latency-bound pieces of one batch run
  *                         beside the next batch's first kernel (3 streams for large batches under reference semantics, 8 for batches <= 32768; fixed-work
  *                         plans with large batches keep the caller's stream), 2 = only OSD-0 + judge on a side stream, 0 = everything on the caller's stream
+ *   "mc_min_launch"       read at plan creation: the smallest piece a code-capacity plan cuts one run call into.  A piece costs ~70 us of host
+ *                         enqueueing whatever its size (4096 shots per piece = 6.8e7 shots/s at most), and the tallies do not depend on the cut
+ *                         (the random stream is keyed by the global shot index), so `batch` values below the granule only bound nothing: the plan
+ *                         sizes its buffers for the granule.  -1 (default) = 32768 for fixed-work plans, 262144 under reference semantics;
+ *                         0 = `batch` literally; otherwise the granule in shots
+ *   "mc_big_lanes"        streams whole batches rotate over under reference semantics with large batches: 2 .. 8 (default 3)
+ *   "mc_list_shots"       shots per workgroup of the full decoder on listed shots: 0 (default: the kernel's own 7), 1 .. 16
  *   "regular_kernel", "wave_cpl", "wave_rst", "wave_grid"  experiments build only: the wave-private decoder (csrc/minsum_wave.hip); the
  *                         product library accepts 0 and answers anything else with QLDPC_ERR_UNSUPPORTED */
 int qldpc_set_option(const char *name, int value);

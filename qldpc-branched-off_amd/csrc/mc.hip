@@ -176,6 +176,14 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
     QLDPC_REQUIRE(max_iter >= 0, "negative max_iter");
     QLDPC_USE_DEVICE(g->device);
     int rc = QLDPC_OK; (void)rc;
+    {   // Launch granule.  A batch costs ~70 us of host time (a dozen enqueues), whatever its size: BASELINE config 2 is quoted at batch 4096, which
+        // is 6.8e7 shots/s of enqueueing however fast the kernels are.  The reference's batch bounds its working set; here it bounds the device
+        // buffers, and the tallies do not depend on it (the random stream is keyed by the global shot index), so a plan never cuts a call into
+        // pieces smaller than the granule (option mc_min_launch; 0 = take `batch` literally).
+        int64_t gran = mc_min_launch_choice();
+        if (gran < 0) gran = (flags & QLDPC_FLAG_FIXED_ITERS) ? 32768 : 262144;
+        if (batch < gran) batch = gran;
+    }
     qldpc_cc_plan *P = new qldpc_cc_plan();
     P->g = g; P->k = k; P->max_iter = max_iter; P->use_osd = use_osd; P->flags = flags;
     P->p = p; P->damping = damping; P->clip = clip_llr; P->batch = batch;

@@ -363,7 +363,7 @@ def test_code_capacity_tally_matches_oracle(L, oracle):
 def options(L):
     """qldpc_set_option switches are process-wide: put the defaults back after a test that turns them"""
     yield L.set_option
-    for name, v in (("mc_first_iteration", 1), ("mc_first_bits", 8), ("mc_tail_overlap", 1)):
+    for name, v in (("mc_first_iteration", 1), ("mc_first_bits", 8), ("mc_tail_overlap", 1), ("mc_min_launch", -1)):
         L.set_option(name, v)
 
 
@@ -390,10 +390,12 @@ def test_first_iteration_pipeline_equals_full_decoder_and_oracle(L, oracle, opti
     c = load_code("bb144")
     graph = L.Graph(c["Hx_indptr"], c["Hx_indices"], c["n"])
     ref = oracle.cc_sample_decode_tally(c["Hx_indptr"], c["Hx_indices"], c["n"], c["Lx"], 0.01, 5, 100, 10000, max_iter=50, threads=0)
-    plan = L.CodeCapacityPlan(graph, c["Lx"], 0.01, max_iter=50, batch=4096)
-    plan.run(5, 100, 10000)
-    assert np.array_equal(plan.read(), ref)
-    plan.close()
+    for granule in (0, -1):            # the batch taken literally (three pieces on the plan's streams), and under the default launch granule
+        options("mc_min_launch", granule)
+        plan = L.CodeCapacityPlan(graph, c["Lx"], 0.01, max_iter=50, batch=4096)
+        plan.run(5, 100, 10000)
+        assert np.array_equal(plan.read(), ref)
+        plan.close()
     c = load_code("steane")
     graph = L.Graph(c["Hx_indptr"], c["Hx_indices"], c["n"])
     ref = oracle.cc_sample_decode_tally(c["Hx_indptr"], c["Hx_indices"], c["n"], c["Lx"], 0.05, 5, 0, 3000, max_iter=50, threads=0)
@@ -801,7 +803,7 @@ def test_osd_order_w_golden(L, golden, oracle):
         performOSD_enhanced(np.asarray(code["Hx"], dtype=np.float64), np.ones(36, np.int8), rng.normal(0, 1, 72), np.zeros(72, np.int8), order=8)
 
 
-def test_full_size_properties(L, oracle):
+def test_full_size_properties(L, oracle, options):
     """BASELINE.json's own sizes, where the oracle would take minutes: size-independent properties of the Monte-Carlo tally.
       * additivity / order independence: the tally of [0, N) equals the sum over any split into sub-ranges, in any order, with any batch;
       * the fixed-work and the early-exit decoders (different kernels paths) agree on every counter;
@@ -814,6 +816,7 @@ def test_full_size_properties(L, oracle):
                              ("bb288", 0.005, 2_000_000, 1 << 20), ("bb288", 0.006, 2_000_000, 1 << 20)):
         c = load_code(tag)
         graph = L.graph_for(c["Hx_indptr"], c["Hx_indices"], c["n"])
+        options("mc_min_launch", 0 if batch == 4096 else -1)          # config 2 with its batch taken literally: 245 pieces on the plan's eight streams
         plan = L.CodeCapacityPlan(graph, c["Lx"], p, max_iter=50, use_osd=True, batch=batch)
         plan.run(7, 0, N)
         whole = plan.read(clear=True)
