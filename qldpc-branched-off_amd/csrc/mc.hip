@@ -146,7 +146,8 @@ struct qldpc_cc_plan {
     bool clk_first = false;               // the last launch stamped the first-iteration kernel's probe buffer
     bool first_ok = false;                // the closed form of iteration 0 applies to this plan (uniform prior > 0, column degree <= 3, ...)
     unsigned negbits = 0;
-    bool fused = false, nanfree = false, clean = false;      // clean: nanfree and |prior| <= clip (what the wave-private kernel needs)
+    bool fused = false, generic = false, nanfree = false, clean = false;      // generic: the fused kernel is the irregular-degree one (minsum_resident.hip)
+    // (clean below)      // clean: nanfree and |prior| <= clip (what the wave-private kernel needs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decode-kernel brackets not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_first;   // ... and those of the first-iteration kernel alone (a part of the bracket above)
@@ -203,6 +204,9 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
     }
     P->fused = !(flags & (QLDPC_FLAG_MC_UNFUSED | QLDPC_FLAG_KERNEL_STREAM | QLDPC_FLAG_KERNEL_GENERIC)) && damping == 1.0 &&
                regular_supported(g, clip_llr, max_iter);
+    if (!P->fused && !(flags & (QLDPC_FLAG_MC_UNFUSED | QLDPC_FLAG_KERNEL_STREAM)) && damping == 1.0 && resident_supported(g, damping)) {
+        P->fused = true; P->generic = true;      // small irregular graphs (Steane, BASELINE config 1), or a regular one asked through QLDPC_FLAG_KERNEL_GENERIC
+    }
     if ((rc = P->d_alpha.ensure(P->alpha.size() * 8)) || (rc = P->d_prior.ensure(prior.size() * 8)) ||
         (rc = P->d_Lmask.ensure(Lmask.size() * 8)) || (rc = P->d_err.ensure(batch * n)) || (rc = P->d_synd.ensure(batch * m)) ||
         (rc = P->d_dec.ensure(batch * n)) || (rc = P->d_llr.ensure(batch * n * 8)) || (rc = P->d_conv.ensure(batch)) ||
@@ -216,7 +220,7 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
         set_error("plan upload failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(QLDPC_ERR_HIP);
     }
-    if (P->fused && !(flags & QLDPC_FLAG_FIXED_ITERS) && max_iter >= 1 && P->clean) {
+    if (P->fused && !P->generic && !(flags & QLDPC_FLAG_FIXED_ITERS) && max_iter >= 1 && P->clean) {
         P->first_ok = mc_first_table(g, prior[0], P->alpha[0], clip_llr, max_iter, P->negbits) && (size_t)(g->m + g->n) * 64 <= 60 * 1024;
         if (P->first_ok) {
             std::vector<int32_t> lptr(k + 1, 0), lidx;
@@ -330,7 +334,10 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
                 rc = mc_wave_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, seed, shot_begin + off,
                                     P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), b_cold.p, s);
 #endif
-            else if ((P->clk_first = false), true)
+            else if ((P->clk_first = false), P->generic)
+                rc = mc_resident_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, seed, shot_begin + off, P->thr,
+                                        P->use_osd, P->d_Lmask.as<uint64_t>(), b_cold.p, s);
+            else
                 rc = mc_regular_launch(g, B, P->d_prior.as<double>(), P->max_iter, P->d_alpha.as<double>(), P->clip, P->flags, P->nanfree, seed,
                                        shot_begin + off, P->thr, P->use_osd, P->d_Lmask.as<uint64_t>(), b_cold.p, s);
             if (rc != QLDPC_OK) return rc;

@@ -43,6 +43,8 @@ int minsum_resident_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd
                            const double *d_alpha, double damping, double clip, int flags, int8_t *d_err, double *d_llr,
                            uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
 bool resident_supported(const qldpc_graph *g, double damping);
+int mc_resident_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int max_iter, const double *d_alpha, double clip, int flags,
+                       uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask, void *d_cold, hipStream_t stream);
 // regular-degree fast path (minsum_regular.hip).  nanfree: the caller proved prior / clip / alphas finite.
 bool regular_supported(const qldpc_graph *g, double clip, int max_iter);
 int minsum_regular_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,

@@ -17,7 +17,9 @@
 //     workgroup leaves the loop when all its shots are frozen (unless QLDPC_FLAG_FIXED_ITERS).
 // No global-memory traffic inside the iteration loop: HBM sees syndromes in, (err, llr, conv, iter) out.
 #include "common.h"
+#include "mc_common.h"
 #include "minsum_common.h"
+#include "minsum_f64.h"
 
 #include <cstdlib>
 
@@ -31,11 +33,20 @@ struct ResidentArgs {
     const int8_t *synd; const double *prior; const double *alpha;
     double damping, clip;
     int8_t *out_err; double *out_llr; uint8_t *out_conv; int32_t *out_iter;
+    // Monte-Carlo mode (MC = true): the sampler, the syndrome, the judge and the tally fused around the decode, as in minsum_regular.hip
+    uint32_t seed_lo, seed_hi, thr; int use_osd;
+    int64_t shot_begin;
+    const uint64_t *Lmask;
+    const RegCold *cold;
 };
 
 template <int CDEG> struct RowStride { static constexpr int value = (CDEG % 2 == 0) ? CDEG + 1 : CDEG; };
 
-template <int CDEG, int VDEG, int CPT, int VPT, bool DAMP>
+// MC = true: a shot is sampled here (Philox4x32-10 stream of mc_common.h keyed by the global shot index, 4 columns per block -- the stream of
+// the regular fused kernel and of the CPU checker), its syndrome is the GF(2) product with the rows (a6), a converged (or, without OSD-0, any)
+// shot is judged against the logical rows and tallied in the kernel, and a BP failure is exported as a record (error, syndrome, hard decision,
+// posteriors) for OSD-0 + the judge of failures -- the irregular small graphs (Steane: BASELINE config 1) get the one-launch pipeline too.
+template <int CDEG, int VDEG, int CPT, int VPT, bool DAMP, bool MC = false>
 __global__ __launch_bounds__(1024) void minsum_resident_kernel(ResidentArgs A) {
     extern __shared__ double smem[];
     constexpr int RST = RowStride<CDEG>::value;
@@ -46,7 +57,16 @@ __global__ __launch_bounds__(1024) void minsum_resident_kernel(ResidentArgs A) {
     double *Vl = smem + (size_t)S * (m * RST) + (size_t)(in_team ? slot : 0) * n;   // V[col]
     int *flags = reinterpret_cast<int *>(smem + (size_t)S * (m * RST) + (size_t)S * n);
     int *unsat = flags + 2 * (in_team ? slot : 0);                          // [2], indexed by iteration parity
-    int *active = flags + 2 * S;
+    int *active = flags + 2 * S;                                            // [0] active shots, [1] (MC) some shot has a record to export
+    // Monte-Carlo state behind the flags: per slot (conv, final iteration, non-zero syndrome, failure index), the logical-row accumulator,
+    // the block tally, the sampled error bytes
+    const int nq = (n + 3) >> 2;
+    int *sres = active + 2 + 4 * (in_team ? slot : 0);
+    unsigned long long *lacc_base = reinterpret_cast<unsigned long long *>(flags + ((2 * S + 2 + 4 * S + 1) & ~1));
+    unsigned long long *lacc = lacc_base + (in_team ? slot : 0);
+    unsigned long long *Tl = lacc_base + S;
+    uint8_t *Eb = reinterpret_cast<uint8_t *>(Tl + 6) + (size_t)(in_team ? slot : 0) * (nq * 4);
+    if (MC && threadIdx.x < 6) Tl[threadIdx.x] = 0ull;
     const double clip = A.clip, damping = A.damping, one_minus_d = 1.0 - A.damping;
 
     // ---- per-thread graph slices, loaded once (registers) ----
@@ -99,8 +119,34 @@ __global__ __launch_bounds__(1024) void minsum_resident_kernel(ResidentArgs A) {
         const int64_t b = base + slot;
         const bool valid = in_team && b < A.B;
         int csyn[CPT];
+        if (MC) {
+            // ---- sample e ~ Bernoulli(p)^n (4 columns per Philox block), s = H e ----
+            if (valid)
+                for (int blk = member; blk < nq; blk += TS) {
+                    const uint64_t gsh = (uint64_t)(A.shot_begin + b);
+                    uint32_t o[4];
+                    philox4x32_10((uint32_t)gsh, (uint32_t)(gsh >> 32), (uint32_t)blk, 0u, A.seed_lo, A.seed_hi, o);
 #pragma unroll
-        for (int c = 0; c < CPT; c++) csyn[c] = (valid && crow[c] >= 0) ? (int)A.synd[b * m + crow[c]] : 0;
+                    for (int t = 0; t < 4; t++) Eb[4 * blk + t] = (4 * blk + t < n && o[t] < A.thr) ? 1 : 0;
+                }
+            if (in_team && member == 0) { sres[0] = 0; sres[1] = 0; sres[2] = 0; sres[3] = -1; *lacc = 0ull; }
+            if (threadIdx.x == 0) active[1] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CPT; c++) {
+                csyn[c] = 0;
+                if (valid && crow[c] >= 0) {
+                    int sy = 0;
+#pragma unroll
+                    for (int k = 0; k < CDEG; k++) if (k < cdeg[c]) sy ^= Eb[ccol[c][k]];
+                    csyn[c] = sy & 1;
+                    if (csyn[c]) sres[2] = 1;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPT; c++) csyn[c] = (valid && crow[c] >= 0) ? (int)A.synd[b * m + crow[c]] : 0;
+        }
         double Rprev[CPT][CDEG], Qold[CPT][CDEG], vval[VPT];
 #pragma unroll
         for (int c = 0; c < CPT; c++)
@@ -179,17 +225,31 @@ __global__ __launch_bounds__(1024) void minsum_resident_kernel(ResidentArgs A) {
                 const bool conv = (it >= 1) && (unsat[it & 1] == 0);                        // kernels.py:361-364
                 if (conv || it == max_iter) {
                     done = true;
+                    if (MC) {
+                        const bool exportit = !conv && A.use_osd;
+                        if (!exportit) {                                                     // judged here: residual error against the logical rows
+                            unsigned long long lm = 0ull;
 #pragma unroll
-                    for (int v = 0; v < VPT; v++)
-                        if (vcol[v] >= 0) {
-                            const double x = (it >= 1) ? vval[v] : 0.0;
-                            A.out_llr[b * n + vcol[v]] = x;
-                            A.out_err[b * n + vcol[v]] = (x < 0) ? 1 : 0;                    // kernels.py:349
+                            for (int v = 0; v < VPT; v++)
+                                if (vcol[v] >= 0 && ((Eb[vcol[v]] ^ ((it >= 1 && vval[v] < 0) ? 1 : 0)) & 1)) lm ^= A.Lmask[vcol[v]];
+                            if (lm) atomicXor(lacc, lm);
+                        } else if (member == 0) {
+                            active[1] = 1;
                         }
-                    if (member == 0) {
-                        A.out_conv[b] = conv ? 1 : 0;
-                        A.out_iter[b] = conv ? it - 1 : max_iter - 1;                        // kernels.py:267,362
-                        atomicSub(active, 1);
+                        if (member == 0) { sres[0] = conv ? 1 : 0; sres[1] = conv ? it - 1 : max_iter - 1; atomicSub(active, 1); }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < VPT; v++)
+                            if (vcol[v] >= 0) {
+                                const double x = (it >= 1) ? vval[v] : 0.0;
+                                A.out_llr[b * n + vcol[v]] = x;
+                                A.out_err[b * n + vcol[v]] = (x < 0) ? 1 : 0;                // kernels.py:349
+                            }
+                        if (member == 0) {
+                            A.out_conv[b] = conv ? 1 : 0;
+                            A.out_iter[b] = conv ? it - 1 : max_iter - 1;                    // kernels.py:267,362
+                            atomicSub(active, 1);
+                        }
                     }
                 }
             }
@@ -210,6 +270,49 @@ __global__ __launch_bounds__(1024) void minsum_resident_kernel(ResidentArgs A) {
             if (!A.fixed && *active == 0) break;
         }
         __syncthreads();   // *active / unsat are re-initialised by the next group
+        if (MC) {
+            if (active[1]) {                        // block-uniform: some shot needs OSD-0 -> export its record
+                const RegCold C = *A.cold;
+                if (valid && member == 0 && sres[0] == 0 && A.use_osd) {
+                    const int f = atomicAdd(C.fail_count, 1);
+                    sres[3] = f;
+                    C.fail_list[f] = f;
+                }
+                __syncthreads();
+                const int f = valid ? sres[3] : -1;
+                if (f >= 0) {
+#pragma unroll
+                    for (int c = 0; c < CPT; c++) if (crow[c] >= 0) C.f_synd[(int64_t)f * m + crow[c]] = (int8_t)csyn[c];
+#pragma unroll
+                    for (int v = 0; v < VPT; v++)
+                        if (vcol[v] >= 0) {
+                            const double xo = (max_iter >= 1) ? vval[v] : 0.0;               // values of the last iteration (what the decode entry point returns)
+                            C.f_llr[(int64_t)f * n + vcol[v]] = xo;
+                            C.f_hard[(int64_t)f * n + vcol[v]] = (xo < 0) ? 1 : 0;
+                            C.f_err[(int64_t)f * n + vcol[v]] = (int8_t)Eb[vcol[v]];
+                        }
+                }
+                __syncthreads();
+            }
+            if ((int)threadIdx.x < S && base + threadIdx.x < A.B) {
+                const int *r = active + 2 + 4 * threadIdx.x;
+                const unsigned long long lm = lacc_base[threadIdx.x];
+                const bool exported = (r[0] == 0) && A.use_osd;
+                atomicAdd(&Tl[0], 1ull);
+                if (r[0]) atomicAdd(&Tl[2], 1ull);
+                atomicAdd(&Tl[3], (unsigned long long)(r[1] + 1));
+                if (!r[2]) atomicAdd(&Tl[4], 1ull);
+                if (!exported) { if (lm) atomicAdd(&Tl[1], 1ull); if (!r[0]) atomicAdd(&Tl[5], 1ull); }
+            }
+            __syncthreads();
+        }
+    }
+    if (MC && threadIdx.x < 6 && Tl[threadIdx.x]) {
+        unsigned long long *tally = A.cold->tally;
+        const unsigned long long v = Tl[threadIdx.x];
+        const int slotmap[6] = {QLDPC_TALLY_TRIALS, QLDPC_TALLY_Z_ERR, QLDPC_TALLY_BP_CONV_Z, QLDPC_TALLY_ITERS_Z, QLDPC_TALLY_ZERO_SYND_Z, QLDPC_TALLY_UNSAT_Z};
+        atomicAdd(&tally[slotmap[threadIdx.x]], v);
+        if (threadIdx.x == 1) atomicAdd(&tally[QLDPC_TALLY_TOTAL_ERR], v);
     }
 }
 
@@ -222,7 +325,7 @@ static bool plan_resident(const qldpc_graph *g, ResidentPlan &P) {
     P.vdeg = g->max_col_deg <= 3 ? 3 : 4;
     if (P.cdeg == 8 || P.vdeg == 4) { P.cdeg = 8; P.vdeg = 4; }
     const int rst = (P.cdeg % 2 == 0) ? P.cdeg + 1 : P.cdeg;
-    const size_t per_slot = ((size_t)g->m * rst + g->n) * 8 + 8;
+    const size_t per_slot = ((size_t)g->m * rst + g->n) * 8 + 8 + 16 + 8 + (size_t)((g->n + 3) / 4) * 4;      // R, V, flags + Monte-Carlo state (results, logical accumulator, error bytes)
     if (per_slot > 60 * 1024) return false;
     // one check / two variables per thread when the team then fits 1024 threads, else two / four
     P.cpt = 1; P.vpt = 2;
@@ -232,10 +335,10 @@ static bool plan_resident(const qldpc_graph *g, ResidentPlan &P) {
     P.TS = ts;
     int S = 1024 / ts;
     const size_t lds_budget = 64 * 1024;   // two workgroups per CU
-    while (S > 1 && (size_t)S * per_slot + 16 > lds_budget) S--;
+    while (S > 1 && (size_t)S * per_slot + 96 > lds_budget) S--;
     if (S < 1) return false;
     P.S = S;
-    P.lds = (size_t)S * per_slot + 16;
+    P.lds = (size_t)S * per_slot + 16 + 16 + 48 + 16;      // + active[2], the block tally, alignment
     return true;
 }
 
@@ -243,6 +346,13 @@ bool resident_supported(const qldpc_graph *g, double damping) {
     (void)damping;
     ResidentPlan P;
     return plan_resident(g, P);
+}
+
+template <int CDEG, int VDEG, int CPT, int VPT>
+static int launch_mc_t(const ResidentArgs &A, unsigned grid, unsigned block, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((minsum_resident_kernel<CDEG, VDEG, CPT, VPT, false, true>), dim3(grid), dim3(block), lds, stream, A);
+    QLDPC_HIP_TRY(hipGetLastError());
+    return QLDPC_OK;
 }
 
 template <int CDEG, int VDEG, int CPT, int VPT>
@@ -273,6 +383,27 @@ int minsum_resident_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     if (P.cdeg == 6 && P.cpt == 2) return launch_t<6, 3, 2, 4>(A, damp, grid, block, P.lds, stream);
     if (P.cdeg == 8 && P.cpt == 1) return launch_t<8, 4, 1, 2>(A, damp, grid, block, P.lds, stream);
     return launch_t<8, 4, 2, 4>(A, damp, grid, block, P.lds, stream);
+}
+
+// the fused Monte-Carlo form (damping == 1): the arguments of mc_regular_launch (minsum_regular.hip), the same record / tally conventions
+int mc_resident_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int max_iter, const double *d_alpha, double clip, int flags,
+                       uint64_t seed, int64_t shot_begin, uint32_t thr, int use_osd, const uint64_t *d_Lmask, void *d_cold, hipStream_t stream) {
+    ResidentPlan P;
+    if (!plan_resident(g, P)) { set_error("graph not supported by the resident kernel"); return QLDPC_ERR_UNSUPPORTED; }
+    ResidentArgs A{};
+    A.m = g->m; A.n = g->n; A.max_iter = max_iter; A.fixed = (flags & QLDPC_FLAG_FIXED_ITERS) ? 1 : 0;
+    A.S = P.S; A.TS = P.TS;
+    A.indptr = g->d_indptr; A.indices = g->d_indices; A.colptr = g->d_colptr; A.rowidx = g->d_rowidx; A.csc2csr = g->d_csc2csr;
+    A.B = B; A.prior = d_prior; A.alpha = d_alpha; A.damping = 1.0; A.clip = clip;
+    A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32); A.thr = thr; A.use_osd = use_osd; A.shot_begin = shot_begin;
+    A.Lmask = d_Lmask; A.cold = reinterpret_cast<const RegCold *>(d_cold);
+    const unsigned block = (unsigned)round_up((int64_t)P.S * P.TS, 64);
+    const int64_t groups = (B + P.S - 1) / P.S, max_grid = 256 * 2 * 8;
+    const unsigned grid = (unsigned)(groups < max_grid ? (groups > 0 ? groups : 1) : max_grid);
+    if (P.cdeg == 6 && P.cpt == 1) return launch_mc_t<6, 3, 1, 2>(A, grid, block, P.lds, stream);
+    if (P.cdeg == 6 && P.cpt == 2) return launch_mc_t<6, 3, 2, 4>(A, grid, block, P.lds, stream);
+    if (P.cdeg == 8 && P.cpt == 1) return launch_mc_t<8, 4, 1, 2>(A, grid, block, P.lds, stream);
+    return launch_mc_t<8, 4, 2, 4>(A, grid, block, P.lds, stream);
 }
 
 }  // namespace qldpc

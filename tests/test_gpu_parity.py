@@ -803,6 +803,26 @@ def test_osd_order_w_golden(L, golden, oracle):
         performOSD_enhanced(np.asarray(code["Hx"], dtype=np.float64), np.ones(36, np.int8), rng.normal(0, 1, 72), np.zeros(72, np.int8), order=8)
 
 
+def test_generic_fused_monte_carlo_equals_oracle(L, oracle, options):
+    """The fused Monte-Carlo form of the irregular-degree resident kernel (csrc/minsum_resident.hip, MC = true: Steane = BASELINE config 1, or any
+    small graph through FLAG_KERNEL_GENERIC) == the unfused sample / decode / judge launches == the oracle: identical tallies with and without
+    OSD-0, under both iteration policies, over several pieces with a ragged tail."""
+    from qldpc_amd.data import load_code
+    options("mc_min_launch", 0)
+    for tag, flags in (("steane", 0), ("bb72", L.FLAG_KERNEL_GENERIC), ("bb144", L.FLAG_KERNEL_GENERIC), ("bb288", L.FLAG_KERNEL_GENERIC)):
+        c = load_code(tag)
+        ip, ix, n = c["Hx_indptr"], c["Hx_indices"], c["n"]
+        graph = L.Graph(ip, ix, n)
+        for p, mi, count, begin, osd in ((0.05, 50, 3000, 0, True), (0.02, 50, 5003, 77, False), (0.1, 3, 2500, 5, True), (0.3, 50, 700, 9, True)):
+            ref = oracle.cc_sample_decode_tally(ip, ix, n, c["Lx"], p, 4242, begin, count, max_iter=mi, use_osd=osd, threads=0)
+            for fl in (flags, flags | L.FLAG_FIXED_ITERS, flags | L.FLAG_MC_UNFUSED):
+                plan = L.CodeCapacityPlan(graph, c["Lx"], p, max_iter=mi, use_osd=osd, flags=fl, batch=1024)
+                plan.run(4242, begin, count)
+                got = plan.read()
+                plan.close()
+                assert np.array_equal(got, ref), (tag, p, mi, osd, fl, got.tolist(), ref.tolist())
+
+
 def test_full_size_properties(L, oracle, options):
     """BASELINE.json's own sizes, where the oracle would take minutes: size-independent properties of the Monte-Carlo tally.
       * additivity / order independence: the tally of [0, N) equals the sum over any split into sub-ranges, in any order, with any batch;
