@@ -127,8 +127,11 @@ __device__ __forceinline__ void gj_rows_apply(unsigned long long *U, const unsig
             const uint32_t dw = row[(pk[k] >> 5) & 31];                                     // (wave-uniform register index)
             mk[k] = ((valid >> k) & 1u) ? __ballot(((dw >> (pk[k] & 31)) & 1u) != 0u) : 0ull;
             touched |= mk[k];
+#ifdef QLDPC_OSD_TIMERS
+            c_gather += (unsigned long long)__builtin_popcountll(mk[k]);                    // (diagnostic build: the count of touched (row, operation) pairs)
+#endif
         }
-        c_gather += OSD_CLOCK() - tg;
+        (void)tg;
         if (touched == 0ull) return;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -153,8 +156,13 @@ __device__ __forceinline__ void gj_rows_apply(unsigned long long *U, const unsig
         for (int k = 0; k < 16; k++) Pw[k] = row32[pk[k] >> 5];
         unsigned long long mk[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) mk[k] = ((valid >> k) & 1u) ? __ballot(((Pw[k] >> (pk[k] & 31)) & 1u) != 0u) : 0ull;
-        c_gather += OSD_CLOCK() - tg;
+        for (int k = 0; k < 16; k++) {
+            mk[k] = ((valid >> k) & 1u) ? __ballot(((Pw[k] >> (pk[k] & 31)) & 1u) != 0u) : 0ull;
+#ifdef QLDPC_OSD_TIMERS
+            c_gather += (unsigned long long)__builtin_popcountll(mk[k]);
+#endif
+        }
+        (void)tg;
         unsigned long long *rowbase = U + qq * mw;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -466,10 +474,9 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
             atomicAdd(&P.dbg[12], c_kill);
         }
 #ifdef QLDPC_OSD_TIMERS
-        if (P.dbg && tid == 0) { atomicAdd(&P.dbg[13], c_own); atomicAdd(&P.dbg[15], c_col); }      // [13] wave 0's pivot chains, [14] the dependent-column
-        if (P.dbg && tid == 64) atomicAdd(&P.dbg[14], c_own);
-        if (P.dbg && tid == 0) atomicAdd(&P.dbg[7], c_gat);                                          // [7] wave 0: phase 3 up to the tested bits
-        if (P.dbg && (tid & 127) == 0) atomicAdd(&P.dbg[24 + (tid >> 7)], c_p3own);                  // [24..31] phase 3 of waves 0, 2, .. 14 without the barrier                                        // tests of wave 1 beside them, [15] block collection
+        if (P.dbg && tid == 0) { atomicAdd(&P.dbg[13], c_own); atomicAdd(&P.dbg[7], c_col); }       // [13] wave 0's pivot chains, [7] block collection
+        if (P.dbg && (tid & 63) == 0) atomicAdd(&P.dbg[15], c_gat);                                  // [15] touched (row, operation) pairs (every wave counts its lanes)
+        if (P.dbg && (tid & 127) == 0) atomicAdd(&P.dbg[24 + (tid >> 7)], c_p3own);                  // [24..31] row updates of waves 0, 2, .. 14 without the barrier
 #endif
         // ---- back-fill (osd.py:19-25): e[pivot col] = reduced rhs at the pivot row; solution = (hard + e) % 2 ----
         __syncthreads();

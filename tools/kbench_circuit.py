@@ -80,8 +80,8 @@ for rep in range(a.reps):
                   f"+ variable {h[21] / h[17]:.0f} + barrier {h[22] / h[17]:.0f}", flush=True)
         if h[0]:
             print(f"  [osd timers] shots={h[0]:.0f} chunks/shot={h[1] / h[0]:.2f} cols/shot={h[2] / h[0]:.1f} pivots/shot={h[3] / h[0]:.1f} kills/shot={h[5] / h[0]:.1f} "
-                  f"blocks/shot={h[6] / h[0]:.1f} kcycles/shot={h[4] / h[0] / 1e3:.1f} (sort {h[8] / h[0] / 1e3:.0f} p1 {h[9] / h[0] / 1e3:.0f} p2 {h[10] / h[0] / 1e3:.0f} "
-                  f"p3 {h[11] / h[0] / 1e3:.0f} kill {h[12] / h[0] / 1e3:.0f} backsub {h[13] / h[0] / 1e3:.0f}; extra counters per shot [7] {h[7] / h[0]:.1f} [14] {h[14] / h[0]:.1f} [15] {h[15] / h[0]:.1f} [24..31] " + " ".join(f"{x / h[0] / 1e3:.0f}" for x in h[24:32]) + ")", flush=True)
+                  f"blocks/shot={h[6] / h[0]:.1f} kcycles/shot={h[4] / h[0] / 1e3:.1f} (sort {h[8] / h[0] / 1e3:.0f} columns+selectors {h[9] / h[0] / 1e3:.0f} chain||rows {h[10] / h[0] / 1e3:.0f} "
+                  f"last rows {h[11] / h[0] / 1e3:.0f} chunk tests {h[12] / h[0] / 1e3:.0f} chain {h[13] / h[0] / 1e3:.0f} collect {h[7] / h[0] / 1e3:.0f}; touched (row, operation) pairs per shot {h[15] / h[0]:.1f}; row updates of waves 0, 2, .. 14 without the barrier, kcycles: " + " ".join(f"{x / h[0] / 1e3:.0f}" for x in h[24:32]) + ")", flush=True)
             if a.counts_out:
                 import json
                 mz = int(d["HdecZ_shape"][0])
@@ -90,8 +90,10 @@ for rep in range(a.reps):
                                "m": mz, "n": int((int(d["HdecZ_shape"][1]) + int(d["HdecX_shape"][1])) / 2), "mw": (mz + 63) // 64,
                                "cdeg": int(max(np.diff(d["HdecZ_indptr"]).max() and 6, 6)), "pivots": round(h[3] / h[0], 1), "cols": round(h[2] / h[0], 1),
                                "blocks": round(h[6] / h[0], 2), "touched": round(h[15] / h[0], 1), "kcycles": round(h[4] / h[0] / 1e3, 1),
-                               "kcycles_by_phase": {"sort": round(h[8] / h[0] / 1e3, 1), "p1": round(h[9] / h[0] / 1e3, 1), "p2": round(h[10] / h[0] / 1e3, 1),
-                                                    "p3": round(h[11] / h[0] / 1e3, 1), "kill": round(h[12] / h[0] / 1e3, 1)}}, fh)
+                               "kcycles_by_phase": {"sort": round(h[8] / h[0] / 1e3, 1), "columns_and_selectors": round(h[9] / h[0] / 1e3, 1),
+                                                    "chain_beside_row_updates": round(h[10] / h[0] / 1e3, 1), "last_row_updates": round(h[11] / h[0] / 1e3, 1),
+                                                    "chunk_start_tests": round(h[12] / h[0] / 1e3, 1), "chain_alone": round(h[13] / h[0] / 1e3, 1),
+                                                    "collect": round(h[7] / h[0] / 1e3, 1)}}, fh)
 
 if a.cpu_trials > 0:
     from oracle import oracle as orc            # CPU checker, timed beside the GPU path (never part of it)

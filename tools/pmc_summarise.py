@@ -64,8 +64,8 @@ def main():
                                              wl["cc_early_exit"]["shots_per_launch"], "shot", regular),
         f"{wl['circuit']}_bp": (lambda k: "minsum_wg_lean_kernel" in k, 2, (cl["iters_z"] + cl["iters_x"]) / 2.0, "decode_iteration",
                                 ["minsum_wg.hip", "minsum_common.h"]),
-        f"{wl['circuit']}_osd": (lambda k: "osd0_lds_kernel" in k, 2, (cl["osd_z"] + cl["osd_x"]) / 2.0, "osd_shot",
-                                 ["gf2.hip", "osd_common.h"]),
+        f"{wl['circuit']}_osd": (lambda k: "osd0_gj_kernel" in k, 2, (cl["osd_z"] + cl["osd_x"]) / 2.0, "osd_shot",
+                                 ["osd_gj.hip", "osd_common.h"]),
     }
     entries, lines = {}, []
     for key, (match, nl, units, unit, sources) in specs.items():
@@ -103,8 +103,8 @@ def main():
             oc = wl["osd_counts"]           # per OSD shot, from the diagnostic build (tools/kbench_circuit.py --timers): pivots, columns through phase 1 / 2, touched (row, operation) pairs
             mw = oc["mw"]
             # word = 64 bits = two 32-bit XORs (2 x 2 cycles).  sort: 8 radix passes x 3 cheap operations per key; column reduction: (deg - 1) word-XORs per
-            # word; the block-local elimination: each pivot updates the (15 / 2 on average) later columns of its block; row updates: one bit test per
-            # (row, operation) pair and mw word-XORs per touched pair
+            # word; the block-local Gauss-Jordan (csrc/osd_gj.hip): each pivot is cleared from the 15 other columns of its block, a selected one takes mw
+            # word-XORs (half of them on average); row updates: one bit test per (row, operation) pair and mw word-XORs per touched pair
             lane_cycles = (oc["n"] * 8 * 3 * 2.0 + oc["cols"] * (oc["cdeg"] - 1) * mw * 4.0 + oc["pivots"] * 7.5 * mw * 4.0 +
                            oc["pivots"] * (oc["m"] + 2) * 2.0 + oc["touched"] * mw * 4.0)
             e["floor_issue_cycles_per_unit"] = round(lane_cycles / 64.0, 1)

@@ -171,7 +171,7 @@ while time.time() < t_end:
         g = graph(tag, ip, ix, n)
         p = float(rng.choice([0.003, 0.01, 0.03, 0.08])); iters = int(rng.integers(1, 55)); use_osd = bool(rng.random() < 0.8)
         batch = int(rng.choice([257, 1000, 4096, 30000, 40000])); seed = int(rng.integers(0, 2 ** 62))
-        flags = int(rng.choice([0, 0, L.FLAG_FIXED_ITERS]))
+        flags = int(rng.choice([0, 0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_GENERIC, L.FLAG_KERNEL_GENERIC | L.FLAG_FIXED_ITERS]))
         L.set_option("mc_first_iteration", int(rng.random() < 0.8)); L.set_option("mc_tail_overlap", int(rng.random() < 0.8))
         L.set_option("mc_min_launch", int(rng.choice([0, 0, 0, -1, 2048])))       # mostly the batch taken literally: several pieces per call
         plan = L.CodeCapacityPlan(g, c["Lx"], p, max_iter=iters, use_osd=use_osd, flags=flags, batch=batch)
@@ -212,7 +212,9 @@ while time.time() < t_end:
         if rng.random() < 0.5:
             llr = np.round(llr)
         hard = (rng.random((B, n)) < 0.01).astype(np.int8)
-        variants = [0, 0, L.FLAG_OSD_UG, L.FLAG_OSD_LDS] + ([L.FLAG_OSD_GLOBAL] if tag == "circ72" else [])
+        if rng.random() < 0.3:
+            llr = np.clip(llr, -4.0, 4.0)                    # many columns at the clip bound: long runs of equal keys
+        variants = [0, 0, 0, L.FLAG_OSD_UG, L.FLAG_OSD_LDS, L.FLAG_OSD_REFORDER] + ([L.FLAG_OSD_GLOBAL] if tag == "circ72" else [])
         env = int(rng.choice(variants))
         sol = L.osd0_batch(g, synd, llr, hard, flags=env)
         for b in range(B):
