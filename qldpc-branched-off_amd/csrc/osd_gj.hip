@@ -387,10 +387,12 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                     }
                     S.live = ~usedw[16 * ub + w];
                     S.nops = 0; S.maxops = P.rankH - row; S.depmask = 0u; S.pivmask = 0u; S.oppv = 0;
+                    {
 #define QLDPC_GSTEP(TT) if (TT < nb && S.nops < S.maxops) gj_pivot_step<TT>(S, lane);
-                    QLDPC_GSTEP(0) QLDPC_GSTEP(1) QLDPC_GSTEP(2) QLDPC_GSTEP(3) QLDPC_GSTEP(4) QLDPC_GSTEP(5) QLDPC_GSTEP(6) QLDPC_GSTEP(7)
-                    QLDPC_GSTEP(8) QLDPC_GSTEP(9) QLDPC_GSTEP(10) QLDPC_GSTEP(11) QLDPC_GSTEP(12) QLDPC_GSTEP(13) QLDPC_GSTEP(14) QLDPC_GSTEP(15)
+                        QLDPC_GSTEP(0) QLDPC_GSTEP(1) QLDPC_GSTEP(2) QLDPC_GSTEP(3) QLDPC_GSTEP(4) QLDPC_GSTEP(5) QLDPC_GSTEP(6) QLDPC_GSTEP(7)
+                        QLDPC_GSTEP(8) QLDPC_GSTEP(9) QLDPC_GSTEP(10) QLDPC_GSTEP(11) QLDPC_GSTEP(12) QLDPC_GSTEP(13) QLDPC_GSTEP(14) QLDPC_GSTEP(15)
 #undef QLDPC_GSTEP
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; i++) if (4 * i + g < nb && w < mw) Cb[(16 * cb + 4 * i + g) * mw + w] = S.X[i];
                     if (g == 0) usedw[16 * (ub ^ 1) + w] = ~S.live;
