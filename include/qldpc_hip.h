@@ -73,6 +73,7 @@ extern "C" {
 #define QLDPC_FLAG_OSD_P3SERIAL 0x10000  /* OSD-0 LDS kernel: row updates test one operation after the other (the round-1 form) */
 #define QLDPC_FLAG_WG_IDXLOAD 0x40000    /* workgroup-per-shot decoder: reload the row's column indices every iteration (m <= 1024 keeps them in registers) */
 #define QLDPC_FLAG_OSD_NOKILL 0x1000     /* OSD-0: no parallel dependent-column tests */
+#define QLDPC_FLAG_OSD_QUEUE 0x100000     /* OSD-0, 897 <= m <= 1024: the free-pivot kernel with a look-ahead queue of reduced columns (csrc/osd_gjq.hip) */
 #define QLDPC_FLAG_OSD_FWD 0x2000        /* OSD-0: the forward-elimination + back-substitution kernel (m <= 1024) */
 
 /* tally slots written by the *_sample_decode_tally entry points (int64[QLDPC_TALLY_SLOTS]);

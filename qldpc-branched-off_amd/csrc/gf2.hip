@@ -1168,7 +1168,7 @@ static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds, int fl
 }
 
 int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
-                   const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled);
+                   const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
 
 int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
                     const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled) {
@@ -1181,7 +1181,7 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
         if (rcs != QLDPC_OK || handled) return rcs;
     }
 #ifndef QLDPC_EXPERIMENTS
-    if (flags & (QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_P2WAVES | QLDPC_FLAG_OSD_P3SERIAL | QLDPC_FLAG_OSD_NOKILL)) {
+    if (flags & (QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_P2WAVES | QLDPC_FLAG_OSD_P3SERIAL | QLDPC_FLAG_OSD_NOKILL | QLDPC_FLAG_OSD_QUEUE)) {
         set_error("this OSD-0 variant (flags %#x) is a measured-and-rejected experiment: it exists in libqldpc_hip_experiments.so only (make experiments)", flags);
         return QLDPC_ERR_UNSUPPORTED;
     }
@@ -1200,7 +1200,7 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
         // m <= 1024: the free-pivot kernel (osd_gj.hip) takes every shot; the ones it lists (right-hand side outside the column space, where the
         // answer depends on the reference's row choice) go through the reference-order kernel below, behind it on the same stream
         bool took = false;
-        const int rcg = osd0_gj_launch(g, d_list, d_count, max_listed, d_synd, d_llr, d_hard, d_ordering, d_solution, stream, took);
+        const int rcg = osd0_gj_launch(g, d_list, d_count, max_listed, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, took);
         if (rcg != QLDPC_OK) return rcg;
         if (took) { d_count = g->ws_redo.as<int32_t>(); d_list = d_count + 4; }
     }

@@ -357,8 +357,10 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
 
 // handled = true when this kernel took the shots.  The shots it could not answer (right-hand side outside the column space) are left in
 // g->ws_redo ([0] count, [4..] shot indices) for the reference-order kernel, which the caller launches behind this one on the same stream.
+int osd0_gjq_launch(const qldpc_graph *g, const OsdGjArgs &base, int grid, hipStream_t stream, bool &launched);
+
 int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
-                   const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled) {
+                   const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled) {
     handled = false;
     if (g->m > 1024 || g->m < 1 || g->n >= 65535 || g->n < 1) return QLDPC_OK;
     OsdGjArgs P;
@@ -396,6 +398,13 @@ int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d
     const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m + 2, 256), 64));
     if ((rc = ensure_max_lds(g->device, reinterpret_cast<const void *>(osd0_gj_kernel<true>), 160 * 1024)) != QLDPC_OK) return rc;
     if ((rc = ensure_max_lds(g->device, reinterpret_cast<const void *>(osd0_gj_kernel<false>), 160 * 1024)) != QLDPC_OK) return rc;
+#ifdef QLDPC_EXPERIMENTS
+    if (P.mw == 16 && block == 1024 && (flags & QLDPC_FLAG_OSD_QUEUE)) {      // the look-ahead-queue form (osd_gjq.hip): measured 25 % slower (profiles/r03_experiments.txt item 12)
+        bool launched = false;
+        if ((rc = osd0_gjq_launch(g, P, grid, stream, launched)) != QLDPC_OK) return rc;
+        if (launched) { handled = true; return QLDPC_OK; }
+    }
+#endif
     if (P.mw == 16 && block == 1024) hipLaunchKernelGGL(osd0_gj_kernel<true>, dim3(grid), dim3(block), lds, stream, P);
     else hipLaunchKernelGGL(osd0_gj_kernel<false>, dim3(grid), dim3(block), lds, stream, P);
     QLDPC_HIP_TRY(hipGetLastError());

@@ -40,7 +40,7 @@ def LX(L):
 
 
 # kernel variants that exist in the experiments build only (include/qldpc_hip.h); the product library refuses them
-XFLAGS = 0x2 | 0x40000 | 0x4 | 0x8 | 0x10000 | 0x1000 | 0x2000      # WG_EDGE_LANES, WG_IDXLOAD, OSD_PIPED, OSD_P2WAVES, OSD_P3SERIAL, OSD_NOKILL, OSD_FWD
+XFLAGS = 0x2 | 0x40000 | 0x4 | 0x8 | 0x10000 | 0x1000 | 0x2000 | 0x100000      # WG_EDGE_LANES, WG_IDXLOAD, OSD_PIPED, OSD_P2WAVES, OSD_P3SERIAL, OSD_NOKILL, OSD_FWD, OSD_QUEUE
 
 
 def for_build(L, variants, key=lambda v: v):
@@ -149,7 +149,7 @@ def test_circuit_level_golden(Lb, golden, oracle, tag):
             assert np.array_equal(sol2, ref2)
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
             # the general global-memory OSD kernel (used when m > 1024) must agree with the LDS-resident one
-            for kfl in for_build(L, (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_REFORDER, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_P2WAVES, L.FLAG_OSD_P3SERIAL)):   # ... and the other forms of the LDS kernel
+            for kfl in for_build(L, (L.FLAG_OSD_GLOBAL, L.FLAG_OSD_REFORDER, L.FLAG_OSD_QUEUE, L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_P2WAVES, L.FLAG_OSD_P3SERIAL)):   # ... and the other forms of the LDS kernel
                 sol3 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, flags=kfl)
                 sol4 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0,
                                            ordering=g[f"{s}_osd_ordering"][t], flags=kfl)
@@ -463,7 +463,7 @@ def test_product_library_refuses_the_experiments(L, oracle):
     for fl in (L.FLAG_WG_EDGE_LANES, L.FLAG_WG_IDXLOAD):
         with pytest.raises(L.QldpcError, match="experiment"):
             L.minsum_decode_batch(graph, synd, prior, 5, "dynamical", 1.0, flags=fl)
-    for fl in (L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_P2WAVES | L.FLAG_OSD_LDS, L.FLAG_OSD_P3SERIAL | L.FLAG_OSD_LDS, L.FLAG_OSD_NOKILL | L.FLAG_OSD_LDS):
+    for fl in (L.FLAG_OSD_FWD, L.FLAG_OSD_PIPED, L.FLAG_OSD_QUEUE, L.FLAG_OSD_P2WAVES | L.FLAG_OSD_LDS, L.FLAG_OSD_P3SERIAL | L.FLAG_OSD_LDS, L.FLAG_OSD_NOKILL | L.FLAG_OSD_LDS):
         with pytest.raises(L.QldpcError, match="experiment"):
             L.osd0_batch(graph, synd, np.ones((2, n)), np.zeros((2, n), np.int8), flags=fl)
     with pytest.raises(L.QldpcError, match="experiment"):
