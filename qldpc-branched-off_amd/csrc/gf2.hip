@@ -1170,6 +1170,9 @@ static int plan_osd_lds(const qldpc_graph *g, OsdLdsArgs &P, size_t &lds, int fl
 int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
 
+int osd0_gjg_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
+                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, size_t ws_offset, bool &handled);
+
 int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
                     const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled) {
     OsdLdsArgs P;
@@ -1195,13 +1198,20 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
         if (rcp != QLDPC_OK || handled) return rcp;
     }
 #endif
-    if (!(flags & (QLDPC_FLAG_OSD_REFORDER | QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL | QLDPC_FLAG_OSD_P2WAVES |
+    if (!(flags & (QLDPC_FLAG_OSD_REFORDER | QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_GLOBAL | QLDPC_FLAG_OSD_P2WAVES |
                    QLDPC_FLAG_OSD_P3SERIAL | QLDPC_FLAG_OSD_NOKILL))) {
-        // m <= 1024: the free-pivot kernel (osd_gj.hip) takes every shot; the ones it lists (right-hand side outside the column space, where the
-        // answer depends on the reference's row choice) go through the reference-order kernel below, behind it on the same stream
+        // the free-pivot kernels take every shot -- osd_gj.hip with the row transform in LDS (m <= 1024), osd_gjg.hip with it in HBM / L2 (m <= 4096, or
+        // asked for by QLDPC_FLAG_OSD_UG); the shots they list (right-hand side outside the column space, where the answer depends on the reference's row
+        // choice) go through the reference-order kernel below, behind them on the same stream
         bool took = false;
-        const int rcg = osd0_gj_launch(g, d_list, d_count, max_listed, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, took);
-        if (rcg != QLDPC_OK) return rcg;
+        if (!(flags & QLDPC_FLAG_OSD_UG)) {
+            const int rcg = osd0_gj_launch(g, d_list, d_count, max_listed, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, took);
+            if (rcg != QLDPC_OK) return rcg;
+        }
+        if (!took) {
+            const int rcg = osd0_gjg_launch(g, d_list, d_count, max_listed, d_synd, d_llr, d_hard, d_ordering, d_solution, stream, 0, took);
+            if (rcg != QLDPC_OK) return rcg;
+        }
         if (took) { d_count = g->ws_redo.as<int32_t>(); d_list = d_count + 4; }
     }
     const int mode = (flags & QLDPC_FLAG_OSD_GLOBAL) ? 0 : plan_osd_lds(g, P, lds, flags);

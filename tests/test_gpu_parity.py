@@ -984,7 +984,7 @@ def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch
             from scipy.sparse import csr_matrix
             H = csr_matrix((np.ones(len(ix), np.int8), ix, ip), shape=(len(ip) - 1, n))
             for t, case in enumerate(g[f"{s}_osd_cases"]):
-                for kfl in (L.FLAG_OSD_UG,):
+                for kfl in (L.FLAG_OSD_UG, L.FLAG_OSD_UG | L.FLAG_OSD_REFORDER):
                     sol = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, ordering=g[f"{s}_osd_ordering"][t],
                                               flags=kfl)
                     assert np.array_equal(sol, g[f"{s}_osd_solution"][t]), (tag, s, t, kfl)
@@ -1118,7 +1118,7 @@ def test_random_matrices_osd0_all_kernels(Lb, oracle, monkeypatch):
         hard = (rng.random((B, n)) < 0.1).astype(np.int8)
         want = np.stack([oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)])
         # (0 = the one-wave literal elimination for m <= 128, n <= 1024, else the transform kernel; FLAG_OSD_LDS forces the latter)
-        for env in for_build(L, (0, L.FLAG_OSD_LDS, L.FLAG_OSD_REFORDER, L.FLAG_OSD_LDS | L.FLAG_OSD_REFORDER, L.FLAG_OSD_LDS | L.FLAG_OSD_P2WAVES, L.FLAG_OSD_LDS | L.FLAG_OSD_P3SERIAL, L.FLAG_OSD_UG, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD,
+        for env in for_build(L, (0, L.FLAG_OSD_LDS, L.FLAG_OSD_REFORDER, L.FLAG_OSD_LDS | L.FLAG_OSD_REFORDER, L.FLAG_OSD_LDS | L.FLAG_OSD_P2WAVES, L.FLAG_OSD_LDS | L.FLAG_OSD_P3SERIAL, L.FLAG_OSD_UG, L.FLAG_OSD_UG | L.FLAG_OSD_REFORDER, L.FLAG_OSD_GLOBAL, L.FLAG_OSD_FWD,
                                  L.FLAG_OSD_PIPED, L.FLAG_OSD_NOKILL)):
             sol = L.osd0_batch(graph, synd, llr, hard, flags=env)
             assert np.array_equal(sol, want), (gi, env, np.flatnonzero((sol != want).any(1)))

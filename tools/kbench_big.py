@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: F401,E402
 import qldpc_amd  # noqa: F401,E402
+from qldpc_amd import _lib  # noqa: E402
 from qldpc_amd.data import load_code  # noqa: E402
 from qldpc_amd.codes.bb_code import BBCodeCircuit  # noqa: E402
 from qldpc_amd.noise.builder import build_decoding_matrices  # noqa: E402

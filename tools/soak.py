@@ -214,7 +214,7 @@ while time.time() < t_end:
         hard = (rng.random((B, n)) < 0.01).astype(np.int8)
         if rng.random() < 0.3:
             llr = np.clip(llr, -4.0, 4.0)                    # many columns at the clip bound: long runs of equal keys
-        variants = [0, 0, 0, L.FLAG_OSD_UG, L.FLAG_OSD_LDS, L.FLAG_OSD_REFORDER] + ([L.FLAG_OSD_GLOBAL] if tag == "circ72" else [])
+        variants = [0, 0, 0, L.FLAG_OSD_UG, L.FLAG_OSD_UG | L.FLAG_OSD_REFORDER, L.FLAG_OSD_LDS, L.FLAG_OSD_REFORDER] + ([L.FLAG_OSD_GLOBAL] if tag == "circ72" else [])
         env = int(rng.choice(variants))
         sol = L.osd0_batch(g, synd, llr, hard, flags=env)
         for b in range(B):
