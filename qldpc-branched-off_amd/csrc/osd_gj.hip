@@ -149,7 +149,7 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
             if (row > 0) {                                                   // a fresh chunk late in the sweep is mostly dependent columns
                 long long tk = OSD_CLOCK();
                 d_kills++;
-                kill_pass(0, L, tid, T, usedw + 16 * (pend ? (ub ^ 1) : ub));
+                kill_pass(0, L, tid, T, usedw + 16 * (pend ? (ub ^ 1) : ub));      // (the whole chunk: a window here lets 15 % more dependent columns into the chains)
                 __syncthreads();
                 c_kill += OSD_CLOCK() - tk;
             }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void osd0_gjg_kernel(OsdGjgArgs PP) {
             if (row > 0) {                                                   // a fresh chunk late in the sweep is mostly dependent columns
                 long long tk = OSD_CLOCK();
                 d_kills++;
-                kill_pass(0, L, tid, T, usedw + 64 * par);
+                kill_pass(0, L, tid, T, usedw + 64 * par);                  // (the whole chunk: a window here lets 25 % more dependent columns into the chains)
                 __syncthreads();
                 c_kill += OSD_CLOCK() - tk;
             }
@@ -251,11 +251,13 @@ __global__ __launch_bounds__(1024) void osd0_gjg_kernel(OsdGjgArgs PP) {
                         const int q = qb + tid;
                         const bool act = (q < ms) && (q != m);
                         const int qq = act ? q : m;                          // idle lanes look at the all-zero row: none of their bits is set
-                        unsigned long long Pw[16], mk[16], touched = 0ull;
+                        uint32_t Pw[16];                                     // the dword that holds the tested bit
+                        unsigned long long mk[16], touched = 0ull;
+                        const uint32_t *U32 = reinterpret_cast<const uint32_t *>(U);
 #pragma unroll
-                        for (int k = 0; k < 16; k++) Pw[k] = ((valid >> k) & 1u) ? U[uix(qq, pk[k] >> 6)] : 0ull;
+                        for (int k = 0; k < 16; k++) Pw[k] = ((valid >> k) & 1u) ? U32[2 * uix(qq, pk[k] >> 6) + ((pk[k] >> 5) & 1)] : 0u;
 #pragma unroll
-                        for (int k = 0; k < 16; k++) { mk[k] = __ballot(((Pw[k] >> (pk[k] & 63)) & 1ull) != 0ull); touched |= mk[k]; }
+                        for (int k = 0; k < 16; k++) { mk[k] = __ballot(((Pw[k] >> (pk[k] & 31)) & 1u) != 0u); touched |= mk[k]; }
                         if (touched == 0ull) continue;
                         const bool mine = (touched >> lane) & 1ull;
                         for (int w0 = 0; w0 < mw; w0 += 16) {

@@ -204,6 +204,11 @@ def run_simulation(Hx, Hz, Lx, Lz, error_rate, num_trials=1000, num_cycles=12, m
                     local_tally += t
             total += parallel.allreduce_tally(local_tally, device=device)           # engine.py:450-457
             done += this
+    try:
+        ph, nbat = plan.phase_times()                                            # hipEvent spans of the plan's batches (an extension: not in the reference's result)
+        extra["phase_ms_per_batch"] = {k: v / max(nbat, 1) for k, v in ph.items()}
+    except _lib.QldpcError:
+        pass
     plan.close()
     if stop_on_errors:
         result = {"logical_error_rate": total_errs / max(1, done), "z_logical_error_rate": z_errs / max(1, done),

@@ -47,4 +47,6 @@ try:
               f"p3 {h[11] / h[0] / 1e3:.0f} [mask conversion {h[14] / h[0] / 1e3:.0f}, decision pass {h[7] / h[0] / 1e3:.0f}] kill {h[12] / h[0] / 1e3:.0f} backsub {h[13] / h[0] / 1e3:.0f})", flush=True)
 except Exception:
     pass
+if "phase_ms_per_batch" in r:
+    print("  phases ms/batch: " + " ".join(f"{k}={v:.1f}" for k, v in r["phase_ms_per_batch"].items()), flush=True)
 print(f"{a.code} x {a.cycles} cycles flags={a.flags:#x}: {a.trials / dt:.1f} trials/s ({dt:.1f}s) LER={r['logical_error_rate']:.3f} conv_z={t[4] / t[0]:.2f} osd={t[6]}+{t[7]} unsat={t[12]}+{t[13]}", flush=True)
