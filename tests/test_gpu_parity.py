@@ -969,9 +969,10 @@ def test_non_finite_priors_follow_the_reference(L, oracle, golden, monkeypatch):
 
 
 def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch):
-    """OSD-0 for 1024 < m <= 4096: the row transform (1 MB per shot at m = 2880) lives in HBM/L2 (osd0_lds_kernel<UG = true>), pivots are
-    resolved with 32 / 64 lanes per column.  Forced on the golden circuit-level cases, then on matrices that need it, against the oracle
-    (consistent and inconsistent syndromes: the latter pin the reference's pivot-ROW choice, not just the pivot columns)."""
+    """OSD-0 for 1024 < m <= 4096: the row transform (1 MB per shot at m = 2880) lives in HBM/L2 -- the free-pivot kernel (csrc/osd_gjg.hip) for every
+    shot, the reference-order kernel (osd0_lds_kernel<UG = true>) for right-hand sides outside the column space or, forced, for all.  Forced on the
+    golden circuit-level cases, then on matrices that need it, against the oracle (consistent and inconsistent syndromes: the latter pin the
+    reference's pivot-ROW choice, not just the pivot columns)."""
     import ctypes as C
     from qldpc_amd.decoding.osd import performOSD_enhanced
     from qldpc_amd.data import load_code, load_circuit_matrices
@@ -1006,10 +1007,11 @@ def test_osd0_with_row_transform_in_global_memory(L, oracle, golden, monkeypatch
         synd[B - 1] = (rng.random(m) < 0.5)                          # almost surely outside the column space
         llr = rng.normal(4.0, 3.0, (B, n)); llr[1, :50] = 0.0        # ties
         hard = (rng.random((B, n)) < 0.002).astype(np.int8)
-        sol = L.osd0_batch(graph, synd, llr, hard)
-        for b in range(B):
-            want = oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b])
-            assert np.array_equal(sol[b], want), (cycles, b, int((sol[b] != want).sum()))
+        want = [oracle.osd0(ip, ix, n, synd[b], llr[b], hard[b]) for b in range(B)]
+        for fl in (0, L.FLAG_OSD_REFORDER):
+            sol = L.osd0_batch(graph, synd, llr, hard, flags=fl)
+            for b in range(B):
+                assert np.array_equal(sol[b], want[b]), (cycles, fl, b, int((sol[b] != want[b]).sum()))
             if b < B - 1:
                 assert np.array_equal(oracle.syndrome_check(ip, ix, sol[b]), synd[b])
 
