@@ -24,8 +24,11 @@ ap.add_argument("--p", type=float, default=0.005)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
 ap.add_argument("--timers", action="store_true", help="load libqldpc_hip_timers.so (make -C csrc timers): in-kernel phase counters")
+ap.add_argument("--build", default="", help="a library file name in csrc/ (A/B builds made by tools/ab_build.sh)")
 a = ap.parse_args()
-if a.timers:
+if a.build:
+    _lib.select_build(a.build)
+elif a.timers:
     _lib.select_build("timers")
 c = load_code(a.code)
 bb = dict(ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
