@@ -65,7 +65,7 @@ def main():
         f"{wl['circuit']}_bp": (lambda k: "minsum_wg_lean_kernel" in k, 2, (cl["iters_z"] + cl["iters_x"]) / 2.0, "decode_iteration",
                                 ["minsum_wg.hip", "minsum_common.h"]),
         f"{wl['circuit']}_osd": (lambda k: "osd0_gj_kernel" in k, 2, (cl["osd_z"] + cl["osd_x"]) / 2.0, "osd_shot",
-                                 ["osd_gj.hip", "osd_common.h"]),
+                                 ["osd_gj.hip", "osd_gj.h", "osd_common.h"]),
     }
     entries, lines = {}, []
     for key, (match, nl, units, unit, sources) in specs.items():
