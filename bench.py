@@ -25,7 +25,7 @@ the launch stream in this run), peak = 1024 SIMDs x (shader clock measured in th
 `efficiency` sets the algorithmic floor of the reference's loop nest (f64 lane-operations, counted in DESIGN.md 5.1)
 against the lane-slots actually issued.  The SURVEY 8d streaming-model bytes stay in `hbm_model` for reference.
 `cpu_baseline` = the C oracle (a port of the reference loop nest, early-exit semantics) on the host cores over a bounded
-sample of the same trial stream (rank 0, N = 1 only); a reported baseline, not the target.
+sample of the same trial stream (rank 0 only, after the timed regions; the other ranks of an N > 1 run wait at the next barrier); a reported baseline, not the target.
 """
 import argparse
 import hashlib
@@ -423,7 +423,7 @@ def worker(args):
         if args.legs == "fixed":
             del out["reference_semantics"]
 
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if rank == 0 and not args.no_cpu_baseline:          # rank 0 alone, after the timed regions (the other ranks wait at the next barrier)
             from oracle import oracle as orc          # the checker / CPU baseline, never the product path
             cores = orc.num_threads()
             probe = 200000        # includes thread start-up; large enough that the rate estimate is meaningful
@@ -469,9 +469,49 @@ def worker(args):
                         "warmup": cl["warmup"], "ms_per_step": cl["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                         "dtype": "f64", "data": "synthetic", "config": cl["config"]})
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(scalars_first(out)), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def scalars_first(out):
+    """The JSON line with every headline number as a TOP-LEVEL SCALAR ahead of the nested objects, so that a record that keeps only scalars
+    (or only the head of the line) still shows config 5, the reference-semantics rate and the roofline fractions."""
+    flat = {}
+    rf = out.get("roofline") or {}
+    flat["roofline_frac"] = rf.get("frac")
+    flat["roofline_issued_frac"] = rf.get("issued_frac")
+    flat["kernel_ms_per_launch"] = rf.get("kernel_ms_per_launch")
+    rs = out.get("reference_semantics") or {}
+    flat["ref_semantics_shots_per_s"] = rs.get("value")
+    flat["ref_semantics_ms_per_step"] = rs.get("ms_per_step")
+    cb = out.get("cpu_baseline") or {}
+    flat["cpu_baseline_shots_per_s"] = cb.get("value")
+    flat["cpu_baseline_cores"] = cb.get("cores")
+    lc = out.get("llr_check") or {}
+    flat["llr_max_abs_diff"] = lc.get("max_abs_diff")
+    cl = out.get("circuit_level") or {}
+    if cl:
+        ph = cl.get("phases_ms_per_step") or {}
+        flat["circuit_trials_per_s"] = cl.get("value")
+        flat["circuit_ms_per_step"] = cl.get("ms_per_step")
+        for k in ("sample", "bp_z", "osd_z", "bp_x", "osd_x", "judge"):
+            flat[f"circuit_{k}_ms"] = ph.get(k)
+        flat["circuit_logical_error_rate"] = cl.get("logical_error_rate")
+        cr = cl.get("roofline") or {}
+        flat["circuit_bp_frac"] = (cr.get("bp") or {}).get("frac")
+        flat["circuit_osd_frac"] = (cr.get("osd") or {}).get("frac")
+        flat["circuit_cpu_baseline_trials_per_s"] = (cl.get("cpu_baseline") or {}).get("value")
+    for pt in (out.get("p_sweep") or {}).get("points", []):
+        tag = f"{pt['p']:g}".replace(".", "p")
+        flat[f"p_sweep_{tag}_shots_per_s"] = pt["value"]
+        flat[f"p_sweep_{tag}_logical_error_rate"] = pt["logical_error_rate"]
+    if out.get("p_sweep"):
+        flat["p_sweep_shots_per_s"] = out["p_sweep"]["value"]
+    line = {k: v for k, v in out.items() if not isinstance(v, (dict, list))}
+    line.update({k: v for k, v in flat.items() if v is not None})
+    line.update({k: v for k, v in out.items() if isinstance(v, (dict, list))})
+    return line
 
 
 def circuit_leg(args, _lib, rank, world, local_rank, stream, barrier, reduce_tally, max_over_ranks):
@@ -555,7 +595,7 @@ def circuit_leg(args, _lib, rank, world, local_rank, stream, barrier, reduce_tal
                               pm_osd.get("floor_issue_cycles_per_unit") if pm_osd else None, "osd_shot"),
         "note": "per launch of one sector, from the exclusive (one-stream) batch",
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as orc            # CPU checker, timed beside the GPU path (never part of it)
         circ = orc.make_circuit(comp, c["Lx"], c["Lz"])
         secs = [orc.make_sector(d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"], int(d[f"Hdec{s}_shape"][1]), orc.prior_llrs(d[f"channel_probs{s}"]),

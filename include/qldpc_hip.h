@@ -68,13 +68,8 @@ extern "C" {
 /* measured-and-rejected kernels: libqldpc_hip_experiments.so only (make -C csrc experiments; same ABI, loaded by the parity tests).  The product
  * library answers these with QLDPC_ERR_UNSUPPORTED.  Numbers: profiles/r02_osd_experiments.txt, r02_bp_lane_mapping.txt, r03_wave_kernel.txt */
 #define QLDPC_FLAG_WG_EDGE_LANES 0x2     /* workgroup-per-shot decoder: check pass with 16 lanes per check and shuffle reductions (SURVEY 7-6 option B) */
-#define QLDPC_FLAG_OSD_PIPED 0x4         /* OSD-0: pivot resolution of block i+1 overlapped with the row updates of block i (512 <= m <= 1024) */
-#define QLDPC_FLAG_OSD_P2WAVES 0x8       /* OSD-0 LDS kernel: pivots of a block resolved by four waves with a barrier per pivot (the round-1 form) */
-#define QLDPC_FLAG_OSD_P3SERIAL 0x10000  /* OSD-0 LDS kernel: row updates test one operation after the other (the round-1 form) */
 #define QLDPC_FLAG_WG_IDXLOAD 0x40000    /* workgroup-per-shot decoder: reload the row's column indices every iteration (m <= 1024 keeps them in registers) */
-#define QLDPC_FLAG_OSD_NOKILL 0x1000     /* OSD-0: no parallel dependent-column tests */
 #define QLDPC_FLAG_OSD_QUEUE 0x100000     /* OSD-0, 897 <= m <= 1024: the free-pivot kernel with a look-ahead queue of reduced columns (csrc/osd_gjq.hip) */
-#define QLDPC_FLAG_OSD_FWD 0x2000        /* OSD-0: the forward-elimination + back-substitution kernel (m <= 1024) */
 
 /* tally slots written by the *_sample_decode_tally entry points (int64[QLDPC_TALLY_SLOTS]);
  * replaces the Python tally loop of src/simulation/engine.py:450-457 */

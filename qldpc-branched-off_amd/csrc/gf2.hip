@@ -660,7 +660,7 @@ QLDPC_EXPORT int qldpc_osdw_batch(const qldpc_graph *g, int64_t B, const int8_t 
 namespace qldpc {
 
 struct OsdLdsArgs {
-    int m, n, mw, rankH, K, cdeg, npad, nokill, p2waves, p3serial;
+    int m, n, mw, rankH, K, cdeg, npad;
     const int32_t *indptr, *indices, *colptr, *rowidx;
     const int32_t *list, *count;
     const int8_t *synd; const double *llr; const int8_t *hard; const int32_t *ordering;
@@ -691,11 +691,6 @@ template <bool UG>
 __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
     extern __shared__ unsigned char lds[];
     const int m = P.m, n = P.n, mw = P.mw, K = P.K, cd = P.cdeg, tid = threadIdx.x, T = blockDim.x;
-#ifdef QLDPC_EXPERIMENTS       // measured-and-rejected forms of the phases (profiles/r02_osd_experiments.txt) exist in the experiments build only
-    const bool x_nokill = P.nokill, x_p2waves = P.p2waves, x_p3serial = P.p3serial;
-#else
-    constexpr bool x_nokill = false, x_p2waves = false, x_p3serial = false;
-#endif
     unsigned long long *U;
     if (UG) U = P.ug + (size_t)blockIdx.x * (size_t)(m + 2) * mw; else U = reinterpret_cast<unsigned long long *>(lds);
     uint16_t *sidx = reinterpret_cast<uint16_t *>(lds + P.offIdx);         // [K] columns of the current chunk
@@ -793,7 +788,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 }
             };
             bool kill_due = false;                                           // a block met dependent columns: test the rest of the chunk (deferred, see phase 2)
-            if (row > 0 && !x_nokill) {                                      // a fresh chunk late in the sweep is mostly dependent columns: one pass up
+            if (row > 0) {                                                  // a fresh chunk late in the sweep is mostly dependent columns: one pass up
                 long long tk = OSD_CLOCK();                                    // front instead of one serial pivot step per dependent column
                 d_kills++;
                 kill_pass(0, tid, T);
@@ -850,7 +845,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 // (1.7 M cycles per shot), one wave per column (1.85 M), four columns resolved inside a wave per barrier (1.75 M);
                 // this form: 1.36 M -- the cost is the dependent ballot -> scalar -> lane-read chain of a step, not the barrier.
                 int nops = 0, anydep = 0;
-                if (!UG && !x_p2waves) {
+                if (!UG) {
                     // rows of <= 16 words: the whole block in wave 0, registers only (quad_pivot_step above); the other waves wait at the barrier
                     if (tid < 64) {
                         const int lane = tid, g = lane & 3, w = lane >> 2, wq = row >> 6;
@@ -968,7 +963,7 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                         }
                     }
                 };
-                if (!x_p3serial && nops > 0) {
+                if (nops > 0) {
                     // rows in LDS: osd_rows_apply (osd_common.h) -- tested bits of the whole block read at once, only touched operations visited;
                     // rows in HBM/L2 (UG): the same scheme written out below on the word-major transform
                     int ppv = opp[tid & 15], ptv = opt[tid & 15];           // operation k's (pp, column) sit in lane k of every 16
@@ -1042,21 +1037,6 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                             }
                         }
                     }
-                } else
-                for (int qb = 0; qb < m + 2; qb += T) {
-                    const int q = rowq(qb);
-                    if (q >= m + 2 || q == m) continue;
-                    for (int k = 0; k < nops; k++) {
-                        const int a = __builtin_amdgcn_readfirstlane(opa[k]), pp = __builtin_amdgcn_readfirstlane(opp[k]), wa = a >> 6, wp = pp >> 6;
-                        const unsigned long long xa = U[uix(q, wa)];
-                        const unsigned long long xp = (wp == wa) ? xa : U[uix(q, wp)];
-                        const bool ba = ((xa >> (a & 63)) & 1ull) != 0ull, bp = ((xp >> (pp & 63)) & 1ull) != 0ull;
-#ifdef QLDPC_OSD_TIMERS
-                        { const unsigned long long bb = __ballot(ba || bp); if (bb) { d_wops++; d_lops += __builtin_popcountll(bb); } }
-#endif
-                        if (ba != bp) swap_bits(q, a, pp);
-                        if (bp) add_mask(q, R + __builtin_amdgcn_readfirstlane(opt[k]) * mw);
-                    }
                 }
                 row += nops;
 #ifdef QLDPC_OSD_TIMERS
@@ -1066,8 +1046,8 @@ __global__ __launch_bounds__(1024) void osd0_lds_kernel(OsdLdsArgs P) {
                 c_p3 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
                 if (row >= P.rankH || row >= m) { finished = true; break; }
                 // ---- dependent columns were met: drop every column of the chunk that is dependent by now ----
-                if (anydep && !x_nokill) {
-                    if (!UG && !x_p2waves) {
+                if (anydep) {
+                    if (!UG) {
                         kill_due = true;                                     // done by the idle waves beside the next block's pivot chain (phase 2 above)
                     } else {
                         d_kills++;
@@ -1115,10 +1095,6 @@ int ensure_col_rows(const qldpc_graph *g) {
     return QLDPC_OK;
 }
 
-int osd0_pipe_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                     const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
-int osd0_fwd_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
 int osd0_small_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled);
 
@@ -1178,28 +1154,17 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     OsdLdsArgs P;
     size_t lds = 0;
     handled = false;
-    if (!(flags & (QLDPC_FLAG_OSD_LDS | QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL | QLDPC_FLAG_OSD_P2WAVES |
-                   QLDPC_FLAG_OSD_P3SERIAL | QLDPC_FLAG_OSD_NOKILL))) {                      // small matrices: the literal elimination, one wave per shot
+    if (!(flags & (QLDPC_FLAG_OSD_LDS | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // small matrices: the literal elimination, one wave per shot
         const int rcs = osd0_small_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, stream, handled);
         if (rcs != QLDPC_OK || handled) return rcs;
     }
 #ifndef QLDPC_EXPERIMENTS
-    if (flags & (QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_P2WAVES | QLDPC_FLAG_OSD_P3SERIAL | QLDPC_FLAG_OSD_NOKILL | QLDPC_FLAG_OSD_QUEUE)) {
+    if (flags & QLDPC_FLAG_OSD_QUEUE) {
         set_error("this OSD-0 variant (flags %#x) is a measured-and-rejected experiment: it exists in libqldpc_hip_experiments.so only (make experiments)", flags);
         return QLDPC_ERR_UNSUPPORTED;
     }
-#else
-    if ((flags & QLDPC_FLAG_OSD_FWD) && !(flags & (QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // the forward-elimination kernel (m <= 1024)
-        const int rcf = osd0_fwd_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
-        if (rcf != QLDPC_OK || handled) return rcf;
-    }
-    if ((flags & QLDPC_FLAG_OSD_PIPED) && !(flags & (QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {   // 512 <= m <= 1024
-        const int rcp = osd0_pipe_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
-        if (rcp != QLDPC_OK || handled) return rcp;
-    }
 #endif
-    if (!(flags & (QLDPC_FLAG_OSD_REFORDER | QLDPC_FLAG_OSD_FWD | QLDPC_FLAG_OSD_PIPED | QLDPC_FLAG_OSD_GLOBAL | QLDPC_FLAG_OSD_P2WAVES |
-                   QLDPC_FLAG_OSD_P3SERIAL | QLDPC_FLAG_OSD_NOKILL))) {
+    if (!(flags & (QLDPC_FLAG_OSD_REFORDER | QLDPC_FLAG_OSD_GLOBAL))) {
         // the free-pivot kernels take every shot -- osd_gj.hip with the row transform in LDS (m <= 1024), osd_gjg.hip with it in HBM / L2 (m <= 4096, or
         // asked for by QLDPC_FLAG_OSD_UG); the shots they list (right-hand side outside the column space, where the answer depends on the reference's row
         // choice) go through the reference-order kernel below, behind them on the same stream
@@ -1232,9 +1197,6 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     P.list = d_list; P.count = d_count; P.synd = d_synd; P.llr = d_llr; P.hard = d_hard; P.ordering = d_ordering; P.solution = d_solution;
     P.clk = g->clk_probe;
     P.dbg = osd_timer_buffer();      // NULL unless built with -DQLDPC_OSD_TIMERS (make timers)
-    P.nokill = (flags & QLDPC_FLAG_OSD_NOKILL) ? 1 : 0;
-    P.p2waves = (flags & QLDPC_FLAG_OSD_P2WAVES) ? 1 : 0;
-    P.p3serial = (flags & QLDPC_FLAG_OSD_P3SERIAL) ? 1 : 0;
     const int block = (int)std::min<int64_t>(1024, round_up(std::max(g->m + 2, 256), 64));
     if ((rc = g->ws_queue.ensure(16)) != QLDPC_OK) return rc;
     P.queue = g->ws_queue.as<int>() + 2;

@@ -1,4 +1,4 @@
-// Shared pieces of the OSD-0 kernels (gf2.hip, osd_fwd.hip).
+// Shared pieces of the OSD-0 kernels (gf2.hip, osd_gj.hip, osd_gjg.hip, osd_small.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>

@@ -15,8 +15,10 @@ def performOSD_enhanced(H, syndrome, llr, hard, order=0, max_combinations=None, 
     produces -- and otherwise scores the flip sets of weight <= order over the order+10 least reliable non-pivot positions
     (osd.py:31-75); both branches run on the device.
 
-    ``ordering`` (extension) pins the elimination order; default is ascending |llr| with ties by ascending index
-    (the reference's np.argsort default kind leaves the tie order implementation-defined).  ``flags`` (extension, order == 0 only)
+    The elimination order is the reference's own expression, ``np.argsort(np.abs(llr))`` (osd.py:11-12), evaluated on the host with the
+    caller's NumPy: its default sort kind leaves the order of equal keys implementation-defined, so taking it from the same NumPy call is
+    what makes this single-shot wrapper a drop-in (the batched device entry points, qldpc_osd0_batch without an ordering, use the stable
+    rule: ascending |llr|, ties by ascending index).  ``ordering`` (extension) pins another order; ``flags`` (extension, order == 0 only)
     selects an OSD-0 kernel variant (QLDPC_FLAG_OSD_*; identical results).
     """
     if order < 0:
@@ -28,10 +30,10 @@ def performOSD_enhanced(H, syndrome, llr, hard, order=0, max_combinations=None, 
     l = f64(llr).reshape(1, -1)
     h = i8(hard).reshape(1, -1)
     sol = np.zeros((1, n), np.int8)
-    op = None
-    if ordering is not None:
-        ordering = i32(ordering).reshape(1, -1)
-        op = ptr(ordering, C.c_int32)
+    if ordering is None:
+        ordering = np.argsort(np.abs(l[0]))                        # osd.py:11-12, literally
+    ordering = i32(ordering).reshape(1, -1)
+    op = ptr(ordering, C.c_int32)
     if order == 0:
         check(lib().qldpc_osd0_batch(g.handle, C.c_int64(1), ptr(s, C.c_int8), ptr(l, C.c_double), ptr(h, C.c_int8), op, int(flags), ptr(sol, C.c_int8)))
     else:
