@@ -113,6 +113,12 @@ int qldpc_device_count(void);
  *   "regular_kernel", "wave_cpl", "wave_rst", "wave_grid"  experiments build only: the wave-private decoder (csrc/minsum_wave.hip); the
  *                         product library accepts 0 and answers anything else with QLDPC_ERR_UNSUPPORTED */
 int qldpc_set_option(const char *name, int value);
+/* A stream of `device` for the `stream` arguments below (a host without PyTorch that drives several plans -- one per device, or several on one
+ * device -- gives each its own; NULL there means the device's default stream).  New here: the reference's counterpart is the worker process
+ * of its pool (src/simulation/engine.py:433-435).  qldpc_stream_sync blocks until everything enqueued on it has finished. */
+int qldpc_stream_create(int device, void **stream);
+int qldpc_stream_sync(int device, void *stream);
+int qldpc_stream_destroy(int device, void *stream);
 
 /* Build a Tanner-graph handle on `device`.  Validates the CSR (monotone indptr, 0 <= col < n, strictly
  * increasing columns per row) and derives the CSC view with per-column ASCENDING check order, which is what

@@ -152,6 +152,34 @@ def set_option(name, value):
     check(lib().qldpc_set_option(name.encode(), int(value)))
 
 
+class Stream:
+    """A HIP stream of `device` owned by this object (qldpc_stream_*); `.ptr` goes where the ABI takes a `stream`."""
+
+    def __init__(self, device=0):
+        require_device()
+        self.device = int(device)
+        self._h = C.c_void_p()
+        check(lib().qldpc_stream_create(self.device, C.byref(self._h)))
+
+    @property
+    def ptr(self):
+        return self._h.value or 0
+
+    def synchronize(self):
+        check(lib().qldpc_stream_sync(self.device, self._h))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            lib().qldpc_stream_destroy(self.device, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def require_device():
     if device_count() <= 0:
         raise QldpcError("no HIP device visible: libqldpc_hip runs on MI355X (gfx950) only and has no CPU fallback")

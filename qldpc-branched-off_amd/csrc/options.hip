@@ -52,3 +52,26 @@ QLDPC_EXPORT int qldpc_set_option(const char *name, int value) {
     qldpc::set_error("unknown option '%s'", name);
     return QLDPC_ERR_INVALID;
 }
+
+// Streams for hosts that do not bring their own runtime (run_simulation(num_workers = N): one plan and one stream per worker).
+QLDPC_EXPORT int qldpc_stream_create(int device, void **stream) {
+    QLDPC_REQUIRE(stream != nullptr, "stream is NULL");
+    QLDPC_USE_DEVICE(device);
+    hipStream_t s = nullptr;
+    QLDPC_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_stream_sync(int device, void *stream) {
+    QLDPC_USE_DEVICE(device);
+    QLDPC_HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    return QLDPC_OK;
+}
+
+QLDPC_EXPORT int qldpc_stream_destroy(int device, void *stream) {
+    if (!stream) return QLDPC_OK;
+    QLDPC_USE_DEVICE(device);
+    QLDPC_HIP_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    return QLDPC_OK;
+}

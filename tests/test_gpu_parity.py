@@ -1257,6 +1257,57 @@ def test_run_simulation_sharded_over_two_ranks(L, tmp_path):
     assert r["logical_errors"] == 37 and r["num_trials"] < 501
 
 
+def _num_workers_case(devices, oracle, golden, L):
+    """run_simulation over the worker list `devices` == the one-plan run == the oracle: tallies, the exact stop trial, estimator factors."""
+    from qldpc_amd.data import load_code, load_precomputed_matrices
+    from qldpc_amd.simulation.engine import run_simulation
+    c = load_code("bb72")
+    g, circ, secs, graphs, priors, masks = _circuit_setup(L, oracle, "circ72", golden)
+    bb = dict(ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+    M = load_precomputed_matrices("circ72")
+    kw = dict(num_cycles=6, maxIter=30, precomputed_matrices=M, base_seed=77, batch=64, **bb)
+    ref = oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], 0.005, 77, 0, 501, max_iter=30, threads=0)
+    one = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=501, devices=[0], **kw)
+    many = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=501, devices=devices, **kw)
+    assert many["num_workers"] == len(devices) and many["devices"] == list(devices) and one["num_workers"] == 1
+    assert np.array_equal(one["tally"], ref) and np.array_equal(many["tally"], ref)
+    for k in ("logical_error_rate", "z_logical_error_rate", "x_logical_error_rate", "num_trials", "logical_errors"):
+        assert one[k] == many[k]
+    # the reference's own keyword (engine.py:204): a request beyond the visible GPUs is capped, never an error; osd_order = 2 as main.py:44 runs it
+    capped = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=501, num_workers=8, osd_order=2, **kw)
+    assert capped["num_workers"] == min(8, L.device_count()) and np.array_equal(capped["tally"], ref)
+    # in-order early stop + estimated factors: the run ends AT the trial the one-plan run ends at, with identical factors
+    kw2 = dict(kw, target_logical_errors=37, alpha_mode="alvarado", alpha_estimation_trials=200, scopt=True)
+    a = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=501, devices=[0], **kw2)
+    b = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=501, devices=devices, **kw2)
+    for k in ("num_trials", "logical_errors", "logical_error_rate", "z_logical_error_rate", "x_logical_error_rate", "alpha_r2_z", "alpha_r2_x", "beta_z", "beta_x"):
+        assert a[k] == b[k], k
+    assert a["logical_errors"] == 37 and a["num_trials"] < 501
+    # a ragged split: more workers than trials in a round, and a worker with an empty range
+    tiny = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=2, devices=list(devices) + [devices[0]], **kw)
+    assert np.array_equal(tiny["tally"], oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], 0.005, 77, 0, 2, max_iter=30, threads=0))
+
+
+def test_run_simulation_num_workers_two_plans_one_card(L, oracle, golden):
+    """run_simulation(num_workers / devices): ONE call drives several plans from one host thread each (the reference's pool of engine.py:433-435 with a
+    worker = a GPU plan).  On this pool: two plans sharing GPU 0."""
+    _num_workers_case([0, 0], oracle, golden, L)
+
+
+def test_two_gpus_run_simulation_num_workers(L, oracle, golden):
+    """The same on two cards: num_workers=None takes every visible GPU."""
+    if L.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from qldpc_amd.data import load_code, load_precomputed_matrices
+    from qldpc_amd.simulation.engine import run_simulation
+    _num_workers_case([0, 1], oracle, golden, L)
+    c = load_code("bb72")
+    bb = dict(ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"], a_y_powers=c["a_y_powers"], b_y_powers=c["b_y_powers"], b_x_powers=c["b_x_powers"])
+    r = run_simulation(c["Hx"], c["Hz"], c["Lx"], c["Lz"], 0.005, num_trials=300, num_cycles=6, maxIter=30, precomputed_matrices=load_precomputed_matrices("circ72"),
+                       base_seed=77, batch=64, **bb)
+    assert r["num_workers"] == L.device_count() and r["devices"] == list(range(L.device_count()))
+
+
 def test_device_resident_decode_osd_check_chain(L, oracle):
     """decode -> OSD-0 on the unconverged shots -> syndrome check entirely on torch CUDA tensors and one non-default stream
     (qldpc_minsum_decode_batch_dev, qldpc_osd0_batch_dev with a device-resident selection, qldpc_gf2_spmv_batch_dev): the device-side
