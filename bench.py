@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 20, help="shots per step per GPU (BASELINE config 2 is quoted at 4096)")
+    ap.add_argument("--min-launch", type=int, default=0, help="launch granule of the code-capacity plan (0 = --batch taken literally; qldpc_cc_plan_create)")
     ap.add_argument("--code", default="bb144", help="bb72 = BASELINE config 2, bb144 = config 3 (headline), bb288 = config 4")
     ap.add_argument("--p", type=float, default=0.005)
     ap.add_argument("--p-sweep", default="", help="comma-separated error rates (BASELINE config 4: --code bb288 --p-sweep 0.004,0.005,0.006): the headline leg once "
@@ -302,7 +303,7 @@ def worker(args):
         def run_leg(flags, p=None, tag="fixed"):
             p = args.p if p is None else p
             plan = _lib.CodeCapacityPlan(graph, code["Lx"], p, max_iter=args.max_iter, use_osd=True, flags=flags | kflag | _lib.FLAG_CLOCK_PROBE,
-                                         batch=B)
+                                         batch=B, min_launch=args.min_launch)
 
             def shot0(step):          # disjoint global shot ranges: step-major, then rank
                 return (step * world + rank) * B
@@ -398,7 +399,7 @@ def worker(args):
             "config": {"workload": f"{label} Hx {m}x{n} nnz={nnz} code-capacity p={args.p} max_iter={args.max_iter} "
                                    f"dynamic alpha, OSD-0 on BP failures, batch={B} shots/step/GPU, fixed-work mode (all {args.max_iter} "
                                    "iterations executed per shot, outputs frozen at convergence)",
-                       "code": args.code, "batch": B, "mode": "fixed_iters", "kernel": args.kernel, "seed": SEED},
+                       "code": args.code, "batch": B, "min_launch": args.min_launch, "mode": "fixed_iters", "kernel": args.kernel, "seed": SEED},
             "roofline": roof_fixed if roof_fixed else {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
                                                         "traffic": None, "kernel_ms_per_launch": round(ms_fixed / max(nl_fixed, 1), 4),
                                                         "clock_mhz": round(clk_fixed, 1) if clk_fixed else None,

@@ -103,11 +103,6 @@ int qldpc_device_count(void);
  *   "mc_tail_overlap"     read at plan creation: 1 (default) = whole batches on the plan's own streams so that the latency-bound pieces of one batch run
  *                         beside the next batch's first kernel (3 streams for large batches under reference semantics, 8 for batches <= 32768; fixed-work
  *                         plans with large batches keep the caller's stream), 2 = only OSD-0 + judge on a side stream, 0 = everything on the caller's stream
- *   "mc_min_launch"       read at plan creation: the smallest piece a code-capacity plan cuts one run call into.  A piece costs ~70 us of host
- *                         enqueueing whatever its size (4096 shots per piece = 6.8e7 shots/s at most), and the tallies do not depend on the cut
- *                         (the random stream is keyed by the global shot index), so `batch` values below the granule only bound nothing: the plan
- *                         sizes its buffers for the granule.  -1 (default) = 32768 for fixed-work plans, 262144 under reference semantics;
- *                         0 = `batch` literally; otherwise the granule in shots
  *   "mc_big_lanes"        streams whole batches rotate over under reference semantics with large batches: 2 .. 8 (default 3)
  *   "mc_list_shots"       shots per workgroup of the full decoder on listed shots: 0 (default: the kernel's own 7), 1 .. 16
  *   "regular_kernel", "wave_cpl", "wave_rst", "wave_grid"  experiments build only: the wave-private decoder (csrc/minsum_wave.hip); the
@@ -213,13 +208,17 @@ int qldpc_cc_sample_decode_tally(const qldpc_graph *g, int k, const uint8_t *L, 
                                  const double *alpha_seq, int alpha_len, double damping, double clip_llr, int use_osd,
                                  int flags, int64_t *tally);
 
-/* MC plan handle: same pipeline, asynchronous, for benchmarking and multi-stream use.  The plan owns device
- * buffers sized for `batch` shots; qldpc_cc_plan_run enqueues one batch on `stream` accumulating into the plan's
- * device tally; qldpc_cc_plan_read synchronises the stream and returns (and optionally clears) the tally. */
+/* MC plan handle: same pipeline, asynchronous, for benchmarking and multi-stream use.  qldpc_cc_plan_run cuts its shot range into pieces of
+ * `batch` shots, each enqueued as one pass of the pipeline accumulating into the plan's device tally; the plan owns device buffers for `batch`
+ * shots per piece in flight (up to 8 pieces for batch <= 32768, up to 3 under reference semantics above that, else 1); qldpc_cc_plan_read
+ * synchronises and returns (and optionally clears) the tally.  `batch` is taken literally.  A piece costs the host three enqueues (decode,
+ * OSD-0, judge; ~10 us each), so small pieces bound the rate from the host side: `min_launch` > batch (an argument of THIS plan, 0 = none) lets
+ * the plan cut at that granule instead, with buffers sized for it -- the tallies do not depend on the cut (the random stream is keyed by the
+ * global shot index), only the memory bound `batch` expressed is given up. */
 typedef struct qldpc_cc_plan qldpc_cc_plan;
 int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t *L, double p, int max_iter, int alpha_mode,
                          double alpha_val, const double *alpha_seq, int alpha_len, double damping, double clip_llr,
-                         int use_osd, int flags, int64_t batch, qldpc_cc_plan **out);
+                         int use_osd, int flags, int64_t batch, int64_t min_launch, qldpc_cc_plan **out);
 /* _run only enqueues: on `stream`, or (option mc_tail_overlap >= 1: reference-semantics plans and plans with batch <= 32768) on streams the plan owns,
  * which start behind everything `stream` held when _run was called; several batches are then in flight at once.  _read waits for `stream` and for
  * the plan's own streams, then copies the tally: it is the only way results leave the plan. */

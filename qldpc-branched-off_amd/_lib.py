@@ -421,14 +421,16 @@ class CodeCapacityPlan:
     """Asynchronous code-capacity Monte-Carlo plan (qldpc_cc_plan_*): device-resident sample -> decode -> tally."""
 
     def __init__(self, graph, L, p, max_iter=50, alpha=1.0, alpha_mode="dynamical", damping=1.0, clip_llr=20.0, use_osd=True,
-                 flags=0, batch=1 << 18):
+                 flags=0, batch=1 << 18, min_launch=0):
+        """batch: shots per piece, taken literally (the plan's device buffers hold `batch` shots per piece in flight).  min_launch (extension): let THIS plan
+        cut its calls at a larger granule instead -- fewer, larger launches; results never depend on the cut."""
         mode, aval, seq = alpha_args(alpha_mode, alpha)
         L = u8(L).reshape(-1, graph.n)
         self.graph = graph
         self._h = C.c_void_p()
         check(lib().qldpc_cc_plan_create(graph.handle, C.c_int(L.shape[0]), ptr(L, C.c_uint8), C.c_double(p), C.c_int(max_iter),
                                          C.c_int(mode), C.c_double(aval), ptr(seq, C.c_double), C.c_int(seq.size), C.c_double(damping),
-                                         C.c_double(clip_llr), C.c_int(int(use_osd)), C.c_int(flags), C.c_int64(batch), C.byref(self._h)))
+                                         C.c_double(clip_llr), C.c_int(int(use_osd)), C.c_int(flags), C.c_int64(batch), C.c_int64(min_launch), C.byref(self._h)))
 
     def run(self, seed, shot_begin, count, stream=0):
         check(lib().qldpc_cc_plan_run(self._h, C.c_uint64(seed), C.c_int64(shot_begin), C.c_int64(count), C.c_void_p(stream)))

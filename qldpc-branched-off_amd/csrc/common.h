@@ -124,6 +124,8 @@ struct qldpc_graph {
     // launch on another stream first waits (hipStreamWaitEvent) for the previous user of the workspaces to finish.
     mutable std::mutex mu;
     mutable qldpc::DevBuf ws_msg, ws_qold, ws_vals, ws_misc, ws_queue, ws_list, ws_prior, ws_redo;
+    mutable qldpc::DevBuf ws_squeue;  // work queue of the one-wave OSD-0 kernels (osd_small.hip): zeroed once, the kernels reset it themselves
+    mutable bool ws_private = false;  // the handle is used from ONE stream only (a private copy owned by a plan lane): no hand-over events
     mutable hipEvent_t ws_event = nullptr;
     mutable hipStream_t ws_stream = nullptr;
     mutable bool ws_used = false;

@@ -93,10 +93,12 @@ void DevBuf::release() {
 using namespace qldpc;
 
 int qldpc_graph::ws_acquire(hipStream_t stream) const {
+    if (ws_private) return QLDPC_OK;
     if (ws_used && stream != ws_stream && ws_event) QLDPC_HIP_TRY(hipStreamWaitEvent(stream, ws_event, 0));
     return QLDPC_OK;
 }
 int qldpc_graph::ws_release(hipStream_t stream) const {
+    if (ws_private) return QLDPC_OK;
     if (!ws_event) QLDPC_HIP_TRY(hipEventCreateWithFlags(&ws_event, hipEventDisableTiming));
     QLDPC_HIP_TRY(hipEventRecord(ws_event, stream));
     ws_stream = stream; ws_used = true;
@@ -256,7 +258,7 @@ QLDPC_EXPORT void qldpc_graph_destroy(qldpc_graph *g) {
                     (void *)g->d_deg_of_col, (void *)g->d_ell_col_s, (void *)g->d_ell_var_s, (void *)g->d_identity})
         if (p) (void)hipFree(p);
     g->ws_prior.release();
-    g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_list.release(); g->ws_redo.release();
+    g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_squeue.release(); g->ws_list.release(); g->ws_redo.release();
     for (auto &e : g->alpha_cache) { if (e.dev) (void)hipFree(e.dev); if (e.pinned) (void)hipHostFree(e.pinned); if (e.ready) (void)hipEventDestroy(e.ready); }
     if (g->ws_event) (void)hipEventDestroy(g->ws_event);
     if (g->pin) (void)hipHostFree(g->pin);

@@ -166,7 +166,7 @@ static hipEvent_t get_event(qldpc_cc_plan *P) {
 
 QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t *L, double p, int max_iter, int alpha_mode,
                                       double alpha_val, const double *alpha_seq, int alpha_len, double damping, double clip_llr,
-                                      int use_osd, int flags, int64_t batch, qldpc_cc_plan **out) {
+                                      int use_osd, int flags, int64_t batch, int64_t min_launch, qldpc_cc_plan **out) {
     QLDPC_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
     QLDPC_REQUIRE(g != nullptr, "graph is NULL");
@@ -177,14 +177,10 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
     QLDPC_REQUIRE(max_iter >= 0, "negative max_iter");
     QLDPC_USE_DEVICE(g->device);
     int rc = QLDPC_OK; (void)rc;
-    {   // Launch granule.  A batch costs ~70 us of host time (a dozen enqueues), whatever its size: BASELINE config 2 is quoted at batch 4096, which
-        // is 6.8e7 shots/s of enqueueing however fast the kernels are.  The reference's batch bounds its working set; here it bounds the device
-        // buffers, and the tallies do not depend on it (the random stream is keyed by the global shot index), so a plan never cuts a call into
-        // pieces smaller than the granule (option mc_min_launch; 0 = take `batch` literally).
-        int64_t gran = mc_min_launch_choice();
-        if (gran < 0) gran = (flags & QLDPC_FLAG_FIXED_ITERS) ? 32768 : 262144;
-        if (batch < gran) batch = gran;
-    }
+    QLDPC_REQUIRE(min_launch >= 0 && min_launch <= ((int64_t)1 << 30), "min_launch out of range");
+    // `batch` is taken literally: a piece is three enqueues (decode, OSD-0, judge).  A caller that prefers fewer, larger launches to the memory bound
+    // passes a granule for THIS plan (include/qldpc_hip.h); the tallies do not depend on the cut.
+    if (batch < min_launch) batch = min_launch;
     qldpc_cc_plan *P = new qldpc_cc_plan();
     P->g = g; P->k = k; P->max_iter = max_iter; P->use_osd = use_osd; P->flags = flags;
     P->p = p; P->damping = damping; P->clip = clip_llr; P->batch = batch;
@@ -213,6 +209,7 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
         (rc = P->d_iter.ensure(batch * 4)) || (rc = P->d_tally.ensure(QLDPC_TALLY_SLOTS * 8)) ||
         (rc = P->d_list.ensure(batch * 4)) || (rc = P->d_count.ensure(16)))
         return fail(rc);
+    if (hipMemset(P->d_count.p, 0, 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
     if (hipMemcpy(P->d_alpha.p, P->alpha.data(), P->alpha.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(P->d_prior.p, prior.data(), prior.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(P->d_Lmask.p, Lmask.data(), Lmask.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
@@ -266,6 +263,7 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
                     (rc = Ln.list.ensure(batch * 4)) || (rc = Ln.count.ensure(16)) || (rc = Ln.cold.ensure(mc_regular_cold_bytes())) ||
                     (P->first_ok && (rc = Ln.cont.ensure(batch * 4))))
                     return fail(rc);
+                if (hipMemset(Ln.count.p, 0, 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
                 if ((rc = mc_regular_fill_cold(Ln.cold.p, P->d_tally.as<unsigned long long>(), Ln.count.as<int32_t>(), Ln.list.as<int32_t>(), Ln.synd.as<int8_t>(),
                                                Ln.err.as<int8_t>(), Ln.dec.as<int8_t>(), Ln.llr.as<double>(),
                                                (flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() : nullptr)) != QLDPC_OK)
@@ -275,7 +273,11 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
                 qldpc_cc_plan::Lane &Ln = P->lanes[i];
                 ok = hipEventCreateWithFlags(&Ln.decoded, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&Ln.tail, hipEventDisableTiming) == hipSuccess;
                 if (ok && P->fan) ok = hipStreamCreateWithFlags(&Ln.st, hipStreamNonBlocking) == hipSuccess;
-                if (ok && P->fan && i > 0 && use_osd && qldpc_graph_create(g->m, g->n, g->indptr.data(), g->indices.data(), g->device, &Ln.g) != QLDPC_OK) return fail(QLDPC_ERR_HIP);
+                // a lane owns a private copy of the graph handle (its OSD-0 workspaces are then used from the lane's stream alone: no hand-over events)
+                if (ok && P->fan && use_osd) {
+                    if (qldpc_graph_create(g->m, g->n, g->indptr.data(), g->indices.data(), g->device, &Ln.g) != QLDPC_OK) return fail(QLDPC_ERR_HIP);
+                    Ln.g->ws_private = true;
+                }
             }
             if (ok && !P->fan && nl == 2) ok = hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) == hipSuccess;
             if (ok && P->fan) ok = hipEventCreateWithFlags(&P->ev_in, hipEventDisableTiming) == hipSuccess;
@@ -314,8 +316,13 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
                 s = Ln->st;
             }
             if (P->side && Ln->tail_pending) QLDPC_HIP_TRY(hipStreamWaitEvent(s, Ln->tail, 0));
-            QLDPC_HIP_TRY(hipMemsetAsync(b_count.p, 0, 16, s));          // [0] BP failures (OSD-0 list), [2] shots handed on by the first iteration
-            hipEvent_t e0 = get_event(P), e1 = get_event(P);
+            // counters of the piece: [0] BP failures (OSD-0 list), [2] shots handed on by the first iteration.  Zero at plan creation; the judge kernel, their
+            // last reader, zeroes them again (without OSD-0 there is no judge: a memset then)
+            if (!P->use_osd) QLDPC_HIP_TRY(hipMemsetAsync(b_count.p, 0, 16, s));
+            // timing brackets of the decode launch: pieces small enough to share the chip with their neighbours have no meaningful span of their own and
+            // a piece costs the host ~10 us per enqueue, so only large pieces and instrumented plans (QLDPC_FLAG_CLOCK_PROBE) carry them
+            const bool timed = (P->flags & QLDPC_FLAG_CLOCK_PROBE) || P->batch > kFanBatch;
+            hipEvent_t e0 = timed ? get_event(P) : nullptr, e1 = timed ? get_event(P) : nullptr;
             if (e0 && e1) QLDPC_HIP_TRY(hipEventRecord(e0, s));
             if (P->first_ok && mc_first_choice() == 1 && wave_kernel_choice() != 2) {
                 // reference semantics: every shot through the bit-sliced first iteration, the few that do not stop there through the full decoder
@@ -354,7 +361,7 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
                 if ((rc = osd0_listed_launch(go, b_list.as<int32_t>(), b_count.as<int32_t>(), B, b_synd.as<int8_t>(), b_llr.as<double>(),
                                              b_dec.as<int8_t>(), nullptr, b_dec.as<int8_t>(), P->flags, ts)) != QLDPC_OK)
                     return rc;
-                if ((rc = judge_failed_launch(g, b_count.as<int32_t>(), P->d_Lmask.as<uint64_t>(), b_err.as<int8_t>(), b_synd.as<int8_t>(),
+                if ((rc = judge_failed_launch(g, b_count.as<int32_t>(), true, P->d_Lmask.as<uint64_t>(), b_err.as<int8_t>(), b_synd.as<int8_t>(),
                                               b_dec.as<int8_t>(), P->d_tally.as<unsigned long long>(), ts)) != QLDPC_OK)
                     return rc;
                 if (P->side) { QLDPC_HIP_TRY(hipEventRecord(Ln->tail, ts)); Ln->tail_pending = true; }
@@ -495,7 +502,7 @@ QLDPC_EXPORT int qldpc_cc_sample_decode_tally(const qldpc_graph *g, int k, const
     qldpc_cc_plan *P = nullptr;
     int64_t batch = count < 1 ? 1 : (count < (1 << 18) ? count : (1 << 18));
     int rc = qldpc_cc_plan_create(g, k, L, p, max_iter, alpha_mode, alpha_val, alpha_seq, alpha_len, damping, clip_llr, use_osd, flags,
-                                  batch, &P);
+                                  batch, 0, &P);
     if (rc != QLDPC_OK) return rc;
     rc = qldpc_cc_plan_run(P, seed, shot_begin, count, nullptr);
     if (rc == QLDPC_OK) rc = qldpc_cc_plan_read(P, nullptr, 0, tally);

@@ -60,13 +60,12 @@ int mc_first_launch(const qldpc_graph *g, int k, const int32_t *d_lptr, const in
 void mc_first_set_bits(int bits);
 void regular_set_list_shots(int s);
 void mc_set_big_lanes(int n);
-int mc_min_launch_choice();    // qldpc_set_option("mc_min_launch"): smallest piece a code-capacity plan cuts a call into (-1 = 32768 fixed-work / 262144 early exit; 0 = the plan's batch, literally)
 int mc_tail_overlap_choice();  // qldpc_set_option("mc_tail_overlap"): 1 = OSD-0 + judge of a batch on a side stream beside the next batch's decode (default)
 int mc_first_choice();       // qldpc_set_option("mc_first_iteration"): 1 = use it where it applies (default), 0 = full decoder for every shot
 int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd,
                          int8_t *f_err, int8_t *f_hard, double *f_llr, unsigned long long *d_clk);
 size_t mc_regular_cold_bytes();
-int judge_failed_launch(const qldpc_graph *g, const int32_t *d_count, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
+int judge_failed_launch(const qldpc_graph *g, int32_t *d_count, bool reset_counters, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
                         const int8_t *f_dec, unsigned long long *d_tally, hipStream_t stream);
 // wave-private kernel for (6,3)-regular graphs and clean inputs (minsum_wave.hip); option "regular_kernel" selects between the two
 bool wave_supported(const qldpc_graph *g, double damping, bool clean);

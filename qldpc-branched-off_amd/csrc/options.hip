@@ -7,11 +7,10 @@
 
 namespace qldpc {
 
-static std::atomic<int> g_opt_kernel{0}, g_opt_first{1}, g_opt_tail{1}, g_opt_min_launch{-1};
+static std::atomic<int> g_opt_kernel{0}, g_opt_first{1}, g_opt_tail{1};
 int wave_kernel_choice() { return g_opt_kernel.load(); }
 int mc_first_choice() { return g_opt_first.load(); }
 int mc_tail_overlap_choice() { return g_opt_tail.load(); }
-int mc_min_launch_choice() { return g_opt_min_launch.load(); }
 #ifdef QLDPC_EXPERIMENTS
 extern std::atomic<int> g_opt_wave_cpl, g_opt_wave_rst, g_opt_wave_grid;      // minsum_wave.hip
 #endif
@@ -32,7 +31,6 @@ QLDPC_EXPORT int qldpc_set_option(const char *name, int value) {
     if (!std::strcmp(name, "mc_first_iteration")) { QLDPC_REQUIRE(value == 0 || value == 1, "mc_first_iteration: 0 or 1"); qldpc::g_opt_first = value; return QLDPC_OK; }
     if (!std::strcmp(name, "mc_tail_overlap")) { QLDPC_REQUIRE(value >= 0 && value <= 2, "mc_tail_overlap: 0, 1 or 2"); qldpc::g_opt_tail = value; return QLDPC_OK; }
     if (!std::strcmp(name, "mc_first_bits")) { QLDPC_REQUIRE(value == 8 || value == 16 || value == 32, "mc_first_bits: 8, 16 or 32"); qldpc::mc_first_set_bits(value); return QLDPC_OK; }
-    if (!std::strcmp(name, "mc_min_launch")) { QLDPC_REQUIRE(value >= -1 && value <= (1 << 24), "mc_min_launch: -1 (default), 0 .. 16777216"); qldpc::g_opt_min_launch = value; return QLDPC_OK; }
     if (!std::strcmp(name, "mc_big_lanes")) { QLDPC_REQUIRE(value >= 2 && value <= 8, "mc_big_lanes: 2 .. 8"); qldpc::mc_set_big_lanes(value); return QLDPC_OK; }
     if (!std::strcmp(name, "mc_list_shots")) { QLDPC_REQUIRE(value >= 0 && value <= 16, "mc_list_shots: 0 .. 16"); qldpc::regular_set_list_shots(value); return QLDPC_OK; }
     const bool wave_opt = !std::strcmp(name, "regular_kernel") || !std::strcmp(name, "wave_cpl") || !std::strcmp(name, "wave_rst") || !std::strcmp(name, "wave_grid");

@@ -25,6 +25,16 @@ struct OsdSmallArgs {
     unsigned long long *clk;
 };
 
+// The work queue resets itself: every workgroup that leaves the loop has read its last (>= total) ticket, so the last one to leave may zero the
+// ticket counter for the next launch -- the host then enqueues ONE call per launch instead of a memset + a kernel (a Monte-Carlo piece of 4096
+// shots costs the host ~10 us per enqueue; csrc/mc.hip).  queue[0] = next ticket, queue[1] = workgroups that have left.
+__device__ __forceinline__ void osd_small_queue_reset(int *queue) {
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(queue + 1, 1) == (int)gridDim.x - 1) { queue[0] = 0; queue[1] = 0; __threadfence(); }
+    }
+}
+
 __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
     extern __shared__ unsigned char lds[];
     const int m = P.m, n = P.n, nw = P.nw, lane = threadIdx.x, rs = nw + 1;              // row stride in words: nw matrix words + the rhs word
@@ -108,6 +118,7 @@ __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
         }
     }
     clk_end(P.clk, clk0);
+    osd_small_queue_reset(P.queue);
 }
 
 // The same with the matrix in REGISTERS (n <= 64 NW columns, NW <= 4): lane r holds rows r and r + 64 (NW matrix words + the rhs each).  The LDS
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(64) void osd0_small_reg_kernel(OsdSmallArgs P) {
         __builtin_amdgcn_wave_barrier();
     }
     clk_end(P.clk, clk0);
+    osd_small_queue_reset(P.queue);
 }
 
 int host_gf2_rank(const qldpc_graph *g);
@@ -230,9 +242,10 @@ int osd0_small_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t
     P.list = d_list; P.count = d_count; P.synd = d_synd; P.llr = d_llr; P.hard = d_hard; P.ordering = d_ordering; P.solution = d_solution;
     P.clk = g->clk_probe;
     int rc;
-    if ((rc = g->ws_queue.ensure(16)) != QLDPC_OK) return rc;
-    P.queue = g->ws_queue.as<int>() + 2;
-    QLDPC_HIP_TRY(hipMemsetAsync(P.queue, 0, 4, stream));
+    const bool fresh = g->ws_squeue.p == nullptr;
+    if ((rc = g->ws_squeue.ensure(16)) != QLDPC_OK) return rc;
+    if (fresh) QLDPC_HIP_TRY(hipMemset(g->ws_squeue.p, 0, 16));         // once per graph handle; the kernels leave the queue zeroed (osd_small_queue_reset)
+    P.queue = g->ws_squeue.as<int>();
     const size_t lds = (size_t)g->m * (P.nw + 1) * 8 + (size_t)g->n * 8 + (size_t)g->n * 2 + (size_t)g->m * 2 + 16;
     const size_t lds_reg = (size_t)g->n * 8 + (size_t)g->n * 2 + (size_t)g->m * 2 + 16;
     switch (P.nw) {                                                  // n <= 256: the rows fit registers

@@ -371,7 +371,7 @@ def test_code_capacity_tally_matches_oracle(L, oracle):
 def options(L):
     """qldpc_set_option switches are process-wide: put the defaults back after a test that turns them"""
     yield L.set_option
-    for name, v in (("mc_first_iteration", 1), ("mc_first_bits", 8), ("mc_tail_overlap", 1), ("mc_min_launch", -1)):
+    for name, v in (("mc_first_iteration", 1), ("mc_first_bits", 8), ("mc_tail_overlap", 1)):
         L.set_option(name, v)
 
 
@@ -398,9 +398,8 @@ def test_first_iteration_pipeline_equals_full_decoder_and_oracle(L, oracle, opti
     c = load_code("bb144")
     graph = L.Graph(c["Hx_indptr"], c["Hx_indices"], c["n"])
     ref = oracle.cc_sample_decode_tally(c["Hx_indptr"], c["Hx_indices"], c["n"], c["Lx"], 0.01, 5, 100, 10000, max_iter=50, threads=0)
-    for granule in (0, -1):            # the batch taken literally (three pieces on the plan's streams), and under the default launch granule
-        options("mc_min_launch", granule)
-        plan = L.CodeCapacityPlan(graph, c["Lx"], 0.01, max_iter=50, batch=4096)
+    for granule in (0, 262144):        # the batch taken literally (three pieces on the plan's streams), and under a launch granule of this plan
+        plan = L.CodeCapacityPlan(graph, c["Lx"], 0.01, max_iter=50, batch=4096, min_launch=granule)
         plan.run(5, 100, 10000)
         assert np.array_equal(plan.read(), ref)
         plan.close()
@@ -816,7 +815,6 @@ def test_generic_fused_monte_carlo_equals_oracle(L, oracle, options):
     small graph through FLAG_KERNEL_GENERIC) == the unfused sample / decode / judge launches == the oracle: identical tallies with and without
     OSD-0, under both iteration policies, over several pieces with a ragged tail."""
     from qldpc_amd.data import load_code
-    options("mc_min_launch", 0)
     for tag, flags in (("steane", 0), ("bb72", L.FLAG_KERNEL_GENERIC), ("bb144", L.FLAG_KERNEL_GENERIC), ("bb288", L.FLAG_KERNEL_GENERIC)):
         c = load_code(tag)
         ip, ix, n = c["Hx_indptr"], c["Hx_indices"], c["n"]
@@ -844,8 +842,7 @@ def test_full_size_properties(L, oracle, options):
                              ("bb288", 0.005, 10_000_000, 1 << 20), ("bb288", 0.006, 10_000_000, 1 << 20)):      # 1e7 shots per point, as BASELINE quotes config 4
         c = load_code(tag)
         graph = L.graph_for(c["Hx_indptr"], c["Hx_indices"], c["n"])
-        options("mc_min_launch", 0 if batch == 4096 else -1)          # config 2 with its batch taken literally: 245 pieces on the plan's eight streams
-        plan = L.CodeCapacityPlan(graph, c["Lx"], p, max_iter=50, use_osd=True, batch=batch)
+        plan = L.CodeCapacityPlan(graph, c["Lx"], p, max_iter=50, use_osd=True, batch=batch)      # config 2: its batch of 4096 taken literally, 245 pieces on the plan's eight streams
         plan.run(7, 0, N)
         whole = plan.read(clear=True)
         cuts = [0, 1, 4097, N // 3, N // 3 + 1_000_003 % N, N]

@@ -17,16 +17,14 @@ ap.add_argument("--code", default="bb72")
 ap.add_argument("--shots", type=int, default=1 << 21)
 ap.add_argument("--batches", default="4096,8192,16384,32768,65536,1048576")
 ap.add_argument("--p", type=float, default=0.005)
-ap.add_argument("--granule", default="", help="mc_min_launch settings to time (default: the library's)")
+ap.add_argument("--granule", default="", help="min_launch values (per-plan launch granule) to time; default 0 = the batch taken literally")
 a = ap.parse_args()
 c = load_code(a.code)
 g = _lib.Graph(c["Hx_indptr"], c["Hx_indices"], c["n"])
-for gran in ([None] if not a.granule else [int(x) for x in a.granule.split(",")]):
-    if gran is not None:
-        _lib.set_option("mc_min_launch", gran)
+for gran in ([0] if not a.granule else [int(x) for x in a.granule.split(",")]):
     for batch in (int(x) for x in a.batches.split(",")):
         for mode, fl in (("fixed", _lib.FLAG_FIXED_ITERS), ("early-exit", 0)):
-            plan = _lib.CodeCapacityPlan(g, c["Lx"], a.p, max_iter=50, flags=fl, batch=batch)
+            plan = _lib.CodeCapacityPlan(g, c["Lx"], a.p, max_iter=50, flags=fl, batch=batch, min_launch=gran)
             plan.run(1, 0, min(a.shots, 8 * batch)); plan.read(clear=True)
             t0 = time.perf_counter()
             plan.run(2, 0, a.shots)

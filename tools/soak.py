@@ -173,8 +173,8 @@ while time.time() < t_end:
         batch = int(rng.choice([257, 1000, 4096, 30000, 40000])); seed = int(rng.integers(0, 2 ** 62))
         flags = int(rng.choice([0, 0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_GENERIC, L.FLAG_KERNEL_GENERIC | L.FLAG_FIXED_ITERS]))
         L.set_option("mc_first_iteration", int(rng.random() < 0.8)); L.set_option("mc_tail_overlap", int(rng.random() < 0.8))
-        L.set_option("mc_min_launch", int(rng.choice([0, 0, 0, -1, 2048])))       # mostly the batch taken literally: several pieces per call
-        plan = L.CodeCapacityPlan(g, c["Lx"], p, max_iter=iters, use_osd=use_osd, flags=flags, batch=batch)
+        plan = L.CodeCapacityPlan(g, c["Lx"], p, max_iter=iters, use_osd=use_osd, flags=flags, batch=batch,
+                                  min_launch=int(rng.choice([0, 0, 0, 32768, 2048])))       # mostly the batch taken literally: several pieces per call
         want = np.zeros(16, np.int64); begin = int(rng.integers(0, 10 ** 9))
         for _ in range(int(rng.integers(1, 4))):
             N = int(rng.integers(1, 3 * batch + 2))
@@ -183,7 +183,7 @@ while time.time() < t_end:
             begin += N
         got = plan.read()
         plan.close()
-        L.set_option("mc_first_iteration", 1); L.set_option("mc_tail_overlap", 1); L.set_option("mc_min_launch", -1)
+        L.set_option("mc_first_iteration", 1); L.set_option("mc_tail_overlap", 1)
         if not np.array_equal(got, want):
             fail(f"plan {tag} p={p} batch={batch} seed={seed} iters={iters} osd={use_osd} flags={flags} got={got.tolist()} want={want.tolist()}")
     elif kind == "tally":
