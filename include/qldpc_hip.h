@@ -63,6 +63,8 @@ extern "C" {
                                           only the shots whose right-hand side lies outside the column space take it; the others cannot tell) */
 #define QLDPC_FLAG_OSD_UG 0x400         /* OSD-0: row transform in HBM/L2 even when it fits LDS (the m > 1024 form) */
 #define QLDPC_FLAG_OSD_GLOBAL 0x800     /* OSD-0: the literal global-memory elimination (general fallback) */
+#define QLDPC_FLAG_WG_TABLES 0x200000   /* workgroup-per-shot decoder: the form with its index tables in HBM/L2 (csrc/minsum_wg.hip; what the *_dev entry points always run)
+                                          even when the prior is known on the host and the LDS-resident form (csrc/minsum_wg2.hip) applies */
 #define QLDPC_FLAG_WG_ROWMAJOR 0x8000   /* workgroup-per-shot decoder: natural row / column order instead of the degree-sorted assignment */
 #define QLDPC_FLAG_CLOCK_PROBE 0x4000   /* plans: workgroups stamp s_memtime / s_memrealtime around their work (see *_plan_clock) */
 /* measured-and-rejected kernels: libqldpc_hip_experiments.so only (make -C csrc experiments; same ABI, loaded by the parity tests).  The product

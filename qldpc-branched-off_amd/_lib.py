@@ -30,7 +30,7 @@ TALLY = {"trials": 0, "z_err": 1, "x_err": 2, "total_err": 3, "bp_conv_z": 4, "b
          "iters_z": 8, "iters_x": 9, "zero_synd_z": 10, "zero_synd_x": 11, "unsat_z": 12, "unsat_x": 13}
 
 FLAG_WG_EDGE_LANES, FLAG_OSD_LDS, FLAG_WG_IDXLOAD = 0x2, 0x20000, 0x40000
-FLAG_OSD_REFORDER, FLAG_OSD_QUEUE = 0x80000, 0x100000
+FLAG_OSD_REFORDER, FLAG_OSD_QUEUE, FLAG_WG_TABLES = 0x80000, 0x100000, 0x200000
 FLAG_WG_VGLOBAL, FLAG_WG_GENERIC, FLAG_OSD_UG, FLAG_OSD_GLOBAL, FLAG_CLOCK_PROBE, FLAG_WG_ROWMAJOR = 0x100, 0x200, 0x400, 0x800, 0x4000, 0x8000
 CIRCUIT_PHASES = ("sample", "bp_z", "osd_z", "bp_x", "osd_x", "judge")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "qldpc_hip.h")

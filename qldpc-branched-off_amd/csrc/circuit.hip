@@ -194,6 +194,7 @@ struct qldpc_circuit_plan {
     uint32_t thr = 0;
     int64_t batch = 0;
     bool nanfree = false;
+    std::vector<double> h_prior_z, h_prior_x;      // the priors on the host: what lets the decode dispatch pick the LDS-resident workgroup kernel (minsum_wg2.hip)
     DevBuf d_loc_type, d_zptr, d_zidx, d_zlog, d_xptr, d_xidx, d_xlog;
     DevBuf d_alpha_z, d_alpha_x, d_prior_z, d_prior_x, d_lm_z, d_lm_x;
     DevBuf d_syn_z, d_syn_x, d_true_z, d_true_x, d_det_z, d_det_x, d_llr_z, d_llr_x, d_conv_z, d_conv_x, d_iter_z, d_iter_x;
@@ -425,6 +426,7 @@ QLDPC_EXPORT int qldpc_circuit_plan_create(const qldpc_circuit_desc *D, const ql
         (rc = up(P->d_xidx, xi)) || (rc = up(P->d_xlog, xl)) || (rc = up(P->d_alpha_z, az)) || (rc = up(P->d_alpha_x, ax)))
         return fail(rc);
     std::vector<double> pz(prior_z, prior_z + gz->n), px(prior_x, prior_x + gx->n);
+    P->h_prior_z = pz; P->h_prior_x = px;
     std::vector<uint64_t> lz(logmask_z, logmask_z + gz->n), lx(logmask_x, logmask_x + gx->n);
     if ((rc = up(P->d_prior_z, pz)) || (rc = up(P->d_prior_x, px)) || (rc = up(P->d_lm_z, lz)) || (rc = up(P->d_lm_x, lx))) return fail(rc);
     const size_t Bz = (size_t)batch;
@@ -457,6 +459,7 @@ static int launch_sampler(qldpc_circuit_plan *P, uint64_t seed, int64_t begin, i
 
 static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B, DevBuf &syn, DevBuf &prior, DevBuf &alpha, DevBuf &det, DevBuf &llr,
                          DevBuf &conv, DevBuf &iter, DevBuf &list, int sector, hipStream_t s) {
+    const std::vector<double> &hp = sector ? P->h_prior_x : P->h_prior_z;
     int rc;
     int32_t *count = P->d_count.as<int32_t>() + 4 * sector;
     const int ph_bp = sector ? QLDPC_PHASE_BP_X : QLDPC_PHASE_BP_Z, ph_osd = sector ? QLDPC_PHASE_OSD_X : QLDPC_PHASE_OSD_Z;
@@ -467,7 +470,7 @@ static int decode_sector(qldpc_circuit_plan *P, const qldpc_graph *g, int64_t B,
         g->clk_probe = (clk && sector == 0) ? clk : nullptr;                  // sector Z carries the probe (one writer per buffer)
         rc = minsum_decode_dispatch(g, B, syn.as<int8_t>(), prior.as<double>(), P->max_iter, alpha.as<double>(), P->damping, P->clip,
                                     (P->flags & QLDPC_FLAG_PUBLIC_MASK) | (P->nanfree ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0),
-                                    P->nanfree, det.as<int8_t>(), llr.as<double>(), conv.as<uint8_t>(), iter.as<int32_t>(), s);
+                                    P->nanfree, det.as<int8_t>(), llr.as<double>(), conv.as<uint8_t>(), iter.as<int32_t>(), s, hp.empty() ? nullptr : hp.data());
         g->clk_probe = nullptr;
     }
     if (rc != QLDPC_OK) return rc;

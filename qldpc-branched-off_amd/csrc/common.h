@@ -142,5 +142,6 @@ struct qldpc_graph {
     mutable size_t pin_cap = 0;
     mutable int gf2_rank = -1;       // rank of H over GF(2), computed on first OSD use
     mutable uint16_t *d_col_rows = nullptr;   // [n][max_col_deg] rows of every column (ascending, padded with m), built on first OSD use
+    mutable void *wg2_cache = nullptr;   // tables of the LDS-resident workgroup decoder per prior (minsum_wg2.hip), built on first use (guarded by mu)
     mutable unsigned long long *clk_probe = nullptr;   // set (under mu) by a plan created with QLDPC_FLAG_CLOCK_PROBE around one launch
 };

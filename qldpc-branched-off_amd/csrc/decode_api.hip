@@ -34,7 +34,7 @@ bool inputs_clean(const double *prior, int n, double clip, const double *alpha, 
 
 static int dispatch_kernel(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
                            const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
-                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
+                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream, const double *h_prior) {
     const bool want_stream = flags & QLDPC_FLAG_KERNEL_STREAM;
     const bool want_res = flags & (QLDPC_FLAG_KERNEL_RESIDENT | QLDPC_FLAG_KERNEL_GENERIC);
     const bool can_res = resident_supported(g, damping);
@@ -53,18 +53,28 @@ static int dispatch_kernel(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     }
     if (!want_stream && can_res)
         return minsum_resident_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
-    if (!want_stream && wg_supported(g, damping))
+    if (!want_stream && wg_supported(g, damping)) {
+        // the prior is known on the host and the inputs are clean: the form with every table in LDS (minsum_wg2.hip), unless a flag asks for a form of the
+        // table kernel (QLDPC_FLAG_WG_TABLES and the layout / experiment selectors)
+        if (h_prior && nanfree && damping == 1.0 && !(flags & (QLDPC_FLAG_WG_TABLES | QLDPC_FLAG_WG_VGLOBAL | QLDPC_FLAG_WG_GENERIC | QLDPC_FLAG_WG_ROWMAJOR |
+                                                                  QLDPC_FLAG_WG_EDGE_LANES | QLDPC_FLAG_WG_IDXLOAD))) {
+            const Wg2Prep *prep = nullptr;
+            const int rcp = wg2_prepare(g, h_prior, &prep);
+            if (rcp != QLDPC_OK) return rcp;
+            if (prep) return minsum_wg2_launch(g, prep, B, d_synd, max_iter, d_alpha, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
+        }
         return minsum_wg_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
+    }
     return minsum_stream_launch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, d_err, d_llr, d_conv, d_iter, stream);
 }
 
 // callers hold g->mu; the graph's device workspaces are handed over in stream order (common.h)
 int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
                            const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
-                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream) {
+                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream, const double *h_prior) {
     int rc = g->ws_acquire(stream);
     if (rc != QLDPC_OK) return rc;
-    rc = dispatch_kernel(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream);
+    rc = dispatch_kernel(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip, flags, nanfree, d_err, d_llr, d_conv, d_iter, stream, h_prior);
     const int rel = g->ws_release(stream);          // always: a failing call may have enqueued launches the next stream has to wait for
     return rc != QLDPC_OK ? rc : rel;
 }
@@ -90,7 +100,7 @@ static int check_decode_args(const qldpc_graph *g, int64_t B, const void *synd, 
 static int decode_dev_impl(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior,
                                                int max_iter, int alpha_mode, double alpha_val, const double *alpha_seq,
                                                int alpha_len, double damping, double clip_llr, int flags, bool prior_finite, bool prior_le_clip, int8_t *d_err,
-                                               double *d_llr, uint8_t *d_conv, int32_t *d_iter, void *stream) {
+                                               double *d_llr, uint8_t *d_conv, int32_t *d_iter, void *stream, const double *h_prior = nullptr) {
     int rc = check_decode_args(g, B, d_synd, d_prior, max_iter, clip_llr, d_err, d_llr, d_conv, d_iter);
     if (rc != QLDPC_OK) return rc;
     QLDPC_USE_DEVICE(g->device);
@@ -106,7 +116,7 @@ static int decode_dev_impl(const qldpc_graph *g, int64_t B, const int8_t *d_synd
     flags = (flags & QLDPC_FLAG_PUBLIC_MASK) | (prior_finite ? QLDPC_FLAG_INTERNAL_PRIOR_FINITE : 0) |
             ((prior_finite && prior_le_clip) ? QLDPC_FLAG_INTERNAL_PRIOR_LE_CLIP : 0);
     return minsum_decode_dispatch(g, B, d_synd, d_prior, max_iter, d_alpha, damping, clip_llr, flags, nanfree, d_err,
-                                  d_llr, d_conv, d_iter, s);
+                                  d_llr, d_conv, d_iter, s, h_prior);
 }
 
 QLDPC_EXPORT int qldpc_minsum_decode_batch_dev(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior,
@@ -146,7 +156,7 @@ QLDPC_EXPORT int qldpc_minsum_decode_batch(const qldpc_graph *g, int64_t B, cons
     rc = decode_dev_impl(g, B, reinterpret_cast<int8_t *>(base + o_synd), reinterpret_cast<double *>(base + o_prior), max_iter, alpha_mode,
                          alpha_val, alpha_seq, alpha_len, damping, clip_llr, flags, prior_finite, prior_le_clip, reinterpret_cast<int8_t *>(base + o_err),
                          reinterpret_cast<double *>(base + o_llr), reinterpret_cast<uint8_t *>(base + o_conv),
-                         reinterpret_cast<int32_t *>(base + o_iter), nullptr);
+                         reinterpret_cast<int32_t *>(base + o_iter), nullptr, prior);
     if (rc != QLDPC_OK) return rc;
     const size_t out_bytes = total - o_llr;
     if (out_bytes <= ((size_t)1 << 20) && out_llr) {

@@ -8,6 +8,7 @@
 // one at/below `row`), so XOR-ing words >= pivot_col/64 reproduces the reference's full-row XOR bit for bit.
 #include "common.h"
 #include "mc_common.h"
+#include "minsum_common.h"
 #include "osd_common.h"
 
 #include <algorithm>
@@ -543,7 +544,7 @@ QLDPC_EXPORT int qldpc_osd0_batch(const qldpc_graph *g, int64_t B, const int8_t 
     {
         std::lock_guard<std::mutex> lk(g->mu);
         rc = osd0_listed_launch(g, dlist.as<int32_t>(), dcnt.as<int32_t>(), B, ds.as<int8_t>(), dl.as<double>(), dh.as<int8_t>(),
-                                ordering ? dord.as<int32_t>() : nullptr, dsol.as<int8_t>(), flags, nullptr);
+                                ordering ? dord.as<int32_t>() : nullptr, dsol.as<int8_t>(), flags & QLDPC_FLAG_PUBLIC_MASK, nullptr);
         if (rc == QLDPC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("OSD-0 kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = QLDPC_ERR_HIP; }
     }
     if (rc != QLDPC_OK) return rc;
@@ -574,7 +575,7 @@ QLDPC_EXPORT int qldpc_osd0_batch_dev(const qldpc_graph *g, int64_t B, const int
         hipLaunchKernelGGL(iota_list_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, list, cnt);
         d_select = list; d_select_count = cnt;
     }
-    return osd0_listed_launch(g, d_select, d_select_count, B, d_syndromes, d_llr, d_hard, d_ordering, d_solution, flags, s);
+    return osd0_listed_launch(g, d_select, d_select_count, B, d_syndromes, d_llr, d_hard, d_ordering, d_solution, flags & QLDPC_FLAG_PUBLIC_MASK, s);
 }
 
 // f1: batched performOSD_enhanced(order, max_combinations) (osd.py:5-77); order == 0 is qldpc_osd0_batch.
@@ -1096,7 +1097,7 @@ int ensure_col_rows(const qldpc_graph *g) {
 }
 
 int osd0_small_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled);
+                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
 
 // rank of H over GF(2) (host, once per graph): the sweep above can stop as soon as this many pivots exist
 int host_gf2_rank(const qldpc_graph *g) {
@@ -1155,7 +1156,7 @@ int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     size_t lds = 0;
     handled = false;
     if (!(flags & (QLDPC_FLAG_OSD_LDS | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // small matrices: the literal elimination, one wave per shot
-        const int rcs = osd0_small_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, stream, handled);
+        const int rcs = osd0_small_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
         if (rcs != QLDPC_OK || handled) return rcs;
     }
 #ifndef QLDPC_EXPERIMENTS

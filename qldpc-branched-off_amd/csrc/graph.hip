@@ -1,5 +1,6 @@
 // Error state, device selection and the Tanner-graph handle of libqldpc_hip.
 #include "common.h"
+#include "minsum_common.h"
 
 #include <algorithm>
 #include <cstring>
@@ -260,6 +261,7 @@ QLDPC_EXPORT void qldpc_graph_destroy(qldpc_graph *g) {
     g->ws_prior.release();
     g->ws_msg.release(); g->ws_qold.release(); g->ws_vals.release(); g->ws_misc.release(); g->ws_io.release(); g->ws_queue.release(); g->ws_squeue.release(); g->ws_list.release(); g->ws_redo.release();
     for (auto &e : g->alpha_cache) { if (e.dev) (void)hipFree(e.dev); if (e.pinned) (void)hipHostFree(e.pinned); if (e.ready) (void)hipEventDestroy(e.ready); }
+    if (g->wg2_cache) qldpc::wg2_cache_free(g->wg2_cache);
     if (g->ws_event) (void)hipEventDestroy(g->ws_event);
     if (g->pin) (void)hipHostFree(g->pin);
     delete g;

@@ -358,10 +358,14 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
                 }
                 const qldpc_graph *go = (Ln && Ln->g) ? Ln->g : g;
                 std::lock_guard<std::mutex> lk(go->mu);
+                // a lane's private handle: nobody else draws tickets from its OSD-0 queue, so the judge kernel (behind the OSD-0 launch on the same
+                // stream) zeroes it for the next piece and the launch skips its memset
+                int *osd_q = nullptr;
+                if (go->ws_private && (rc = osd_small_queue(go, &osd_q)) != QLDPC_OK) return rc;
                 if ((rc = osd0_listed_launch(go, b_list.as<int32_t>(), b_count.as<int32_t>(), B, b_synd.as<int8_t>(), b_llr.as<double>(),
-                                             b_dec.as<int8_t>(), nullptr, b_dec.as<int8_t>(), P->flags, ts)) != QLDPC_OK)
+                                             b_dec.as<int8_t>(), nullptr, b_dec.as<int8_t>(), (P->flags & QLDPC_FLAG_PUBLIC_MASK) | (osd_q ? QLDPC_FLAG_INTERNAL_OSD_QUEUE_CLEAN : 0), ts)) != QLDPC_OK)
                     return rc;
-                if ((rc = judge_failed_launch(g, b_count.as<int32_t>(), true, P->d_Lmask.as<uint64_t>(), b_err.as<int8_t>(), b_synd.as<int8_t>(),
+                if ((rc = judge_failed_launch(g, b_count.as<int32_t>(), true, osd_q, P->d_Lmask.as<uint64_t>(), b_err.as<int8_t>(), b_synd.as<int8_t>(),
                                               b_dec.as<int8_t>(), P->d_tally.as<unsigned long long>(), ts)) != QLDPC_OK)
                     return rc;
                 if (P->side) { QLDPC_HIP_TRY(hipEventRecord(Ln->tail, ts)); Ln->tail_pending = true; }

@@ -26,6 +26,7 @@ __device__ __forceinline__ bool prior_not_finite(double p) { return !(fabs(p) < 
 #define QLDPC_FLAG_PUBLIC_MASK 0x0FFFFFFF          // flag bits callers may set (include/qldpc_hip.h)
 #define QLDPC_FLAG_INTERNAL_PRIOR_FINITE 0x40000000
 #define QLDPC_FLAG_INTERNAL_PRIOR_LE_CLIP 0x20000000   // ... and every |prior| <= clip (iteration 0 then needs no unclipped special case)
+#define QLDPC_FLAG_INTERNAL_OSD_QUEUE_CLEAN 0x10000000 // OSD-0 launches: the handle's small-kernel ticket counter is zero and the caller zeroes it again afterwards
 
 // reference src/decoding/kernels.py:339-342
 __device__ __forceinline__ double clip_only(double q, double clip) {
@@ -65,8 +66,9 @@ int mc_first_choice();       // qldpc_set_option("mc_first_iteration"): 1 = use 
 int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_fail_count, int32_t *d_fail_list, int8_t *f_synd,
                          int8_t *f_err, int8_t *f_hard, double *f_llr, unsigned long long *d_clk);
 size_t mc_regular_cold_bytes();
-int judge_failed_launch(const qldpc_graph *g, int32_t *d_count, bool reset_counters, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
+int judge_failed_launch(const qldpc_graph *g, int32_t *d_count, bool reset_counters, int *d_osd_queue, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
                         const int8_t *f_dec, unsigned long long *d_tally, hipStream_t stream);
+int osd_small_queue(const qldpc_graph *g, int **queue);      // osd_small.hip
 // wave-private kernel for (6,3)-regular graphs and clean inputs (minsum_wave.hip); option "regular_kernel" selects between the two
 bool wave_supported(const qldpc_graph *g, double damping, bool clean);
 int wave_kernel_choice();     // 0 automatic, 1 team kernel, 2 wave kernel (qldpc_set_option)
@@ -78,11 +80,18 @@ int mc_wave_launch(const qldpc_graph *g, int64_t B, const double *d_prior, int m
 bool wg_supported(const qldpc_graph *g, double damping);
 int minsum_wg_launch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter, const double *d_alpha,
                      double damping, double clip, int flags, bool clean, int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
+// LDS-resident form of that kernel for callers whose prior is known on the host (minsum_wg2.hip); *out = NULL when the input is not eligible
+struct Wg2Prep;
+int wg2_prepare(const qldpc_graph *g, const double *h_prior, const Wg2Prep **out);
+int minsum_wg2_launch(const qldpc_graph *g, const Wg2Prep *P, int64_t B, const int8_t *d_synd, int max_iter, const double *d_alpha, double clip, int flags,
+                      int8_t *d_err, double *d_llr, uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
+void wg2_cache_free(void *cache);
 // "clean" decoder inputs, verified on the host: every prior finite and not -0.0, clip finite > 0, every alpha finite > 0.
 // Then no message or posterior can be -0.0 and no |q| NaN, which the regular and lean kernels exploit (see their headers).
 bool inputs_clean(const double *prior, int n, double clip, const double *alpha, int n_alpha);
+// h_prior: the same prior on the host when the caller has it (a circuit plan, the host-pointer entry point), else NULL
 int minsum_decode_dispatch(const qldpc_graph *g, int64_t B, const int8_t *d_synd, const double *d_prior, int max_iter,
                            const double *d_alpha, double damping, double clip, int flags, bool nanfree, int8_t *d_err, double *d_llr,
-                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream);
+                           uint8_t *d_conv, int32_t *d_iter, hipStream_t stream, const double *h_prior = nullptr);
 
 }  // namespace qldpc

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(QLDPC_LB_T, QLDPC_LB_W) void minsum_regular_kernel(
 // judge of the exported failures after OSD-0: logical error / unsat / OSD count (32 lanes per record, device-side count)
 // reset != 0: the LAST workgroup to finish zeroes the piece's counters (count[0] failures, count[2] shots the first iteration handed on; count[3] counts
 // finished workgroups) -- every workgroup reads `total` before it can be counted as finished, so the next piece on this lane needs no memset from the host
-__global__ __launch_bounds__(256) void cc_judge_failed_kernel(int32_t *__restrict__ count, int reset, int m, int n,
+__global__ __launch_bounds__(256) void cc_judge_failed_kernel(int32_t *__restrict__ count, int reset, int *__restrict__ osd_queue, int m, int n,
                                                               const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                               const uint64_t *__restrict__ Lmask, const int8_t *__restrict__ err,
                                                               const int8_t *__restrict__ synd, const int8_t *__restrict__ dec,
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void cc_judge_failed_kernel(int32_t *__restric
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence();
-            if (atomicAdd(&count[3], 1) == (int)gridDim.x - 1) { count[0] = 0; count[2] = 0; count[3] = 0; __threadfence(); }
+            if (atomicAdd(&count[3], 1) == (int)gridDim.x - 1) { count[0] = 0; count[2] = 0; count[3] = 0; if (osd_queue) *osd_queue = 0; __threadfence(); }
         }
     }
 }
@@ -505,9 +505,9 @@ int mc_regular_fill_cold(void *d_cold, unsigned long long *d_tally, int32_t *d_f
 }
 size_t mc_regular_cold_bytes() { return sizeof(RegCold); }
 
-int judge_failed_launch(const qldpc_graph *g, int32_t *d_count, bool reset_counters, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
+int judge_failed_launch(const qldpc_graph *g, int32_t *d_count, bool reset_counters, int *d_osd_queue, const uint64_t *d_Lmask, const int8_t *f_err, const int8_t *f_synd,
                         const int8_t *f_dec, unsigned long long *d_tally, hipStream_t stream) {
-    hipLaunchKernelGGL(cc_judge_failed_kernel, dim3(64), dim3(256), 0, stream, d_count, reset_counters ? 1 : 0, g->m, g->n, g->d_indptr, g->d_indices, d_Lmask, f_err,
+    hipLaunchKernelGGL(cc_judge_failed_kernel, dim3(64), dim3(256), 0, stream, d_count, reset_counters ? 1 : 0, d_osd_queue, g->m, g->n, g->d_indptr, g->d_indices, d_Lmask, f_err,
                        f_synd, f_dec, d_tally);
     QLDPC_HIP_TRY(hipGetLastError());
     return QLDPC_OK;

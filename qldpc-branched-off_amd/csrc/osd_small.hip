@@ -9,6 +9,7 @@
 // is added to (kernels.py:88-92).  A lane owns rows lane and lane + 64; one wave, so no barrier: LDS operations of a wave execute in order.
 #include "common.h"
 #include "mc_common.h"
+#include "minsum_common.h"
 #include "osd_common.h"
 
 #include <algorithm>
@@ -25,16 +26,9 @@ struct OsdSmallArgs {
     unsigned long long *clk;
 };
 
-// The work queue resets itself: every workgroup that leaves the loop has read its last (>= total) ticket, so the last one to leave may zero the
-// ticket counter for the next launch -- the host then enqueues ONE call per launch instead of a memset + a kernel (a Monte-Carlo piece of 4096
-// shots costs the host ~10 us per enqueue; csrc/mc.hip).  queue[0] = next ticket, queue[1] = workgroups that have left.
-__device__ __forceinline__ void osd_small_queue_reset(int *queue) {
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(queue + 1, 1) == (int)gridDim.x - 1) { queue[0] = 0; queue[1] = 0; __threadfence(); }
-    }
-}
-
+// Work hand-out: workgroup b takes list entry b without asking, further entries come from a ticket counter (tickets start at gridDim.x).  A launch over
+// a handful of failures -- what a Monte-Carlo piece of a few thousand shots produces -- then issues no atomic at all: 2048 workgroups drawing a ticket
+// each from one address took ~60 us per launch, more than the piece's decode.
 __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
     extern __shared__ unsigned char lds[];
     const int m = P.m, n = P.n, nw = P.nw, lane = threadIdx.x, rs = nw + 1;              // row stride in words: nw matrix words + the rhs word
@@ -44,11 +38,7 @@ __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
     uint16_t *pivcol = ord + n;                                                             // [m] column of the pivot at position t
     const ClkStamp clk0 = clk_begin(P.clk);
     const int total = *P.count;
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(P.queue, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= total) break;
+    for (int item = blockIdx.x; item < total;) {
         const int64_t shot = P.list[item];
         const double *llr = P.llr + shot * n;
         const int8_t *hard = P.hard + shot * n, *synd = P.synd + shot * m;
@@ -116,9 +106,13 @@ __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
             const int j = pivcol[t];
             sol[j] = (int8_t)((hard[j] ^ (int8_t)(A[(size_t)t * rs + nw] & 1ull)) & 1);
         }
+        {   // next entry: a ticket (the first gridDim.x entries were handed out by workgroup index)
+            int t = 0;
+            if (lane == 0) t = atomicAdd(P.queue, 1);
+            item = (int)gridDim.x + __builtin_amdgcn_readfirstlane(t);
+        }
     }
     clk_end(P.clk, clk0);
-    osd_small_queue_reset(P.queue);
 }
 
 // The same with the matrix in REGISTERS (n <= 64 NW columns, NW <= 4): lane r holds rows r and r + 64 (NW matrix words + the rhs each).  The LDS
@@ -146,11 +140,7 @@ __global__ __launch_bounds__(64) void osd0_small_reg_kernel(OsdSmallArgs P) {
     const ClkStamp clk0 = clk_begin(P.clk);
     const int total = *P.count;
     const int r0 = lane, r1 = lane + 64;
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(P.queue, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= total) break;
+    for (int item = blockIdx.x; item < total;) {
         const int64_t shot = P.list[item];
         const double *llr = P.llr + shot * n;
         const int8_t *hard = P.hard + shot * n, *synd = P.synd + shot * m;
@@ -222,16 +212,30 @@ __global__ __launch_bounds__(64) void osd0_small_reg_kernel(OsdSmallArgs P) {
         if (pos0 < rank) { const int jj = pivcol[pos0]; sol[jj] = (int8_t)((hard[jj] ^ (int8_t)(a[0][NW] & 1ull)) & 1); }
         if (pos1 < rank) { const int jj = pivcol[pos1]; sol[jj] = (int8_t)((hard[jj] ^ (int8_t)(a[1][NW] & 1ull)) & 1); }
         __builtin_amdgcn_wave_barrier();
+        {   // next entry: a ticket (the first gridDim.x entries were handed out by workgroup index)
+            int t = 0;
+            if (lane == 0) t = atomicAdd(P.queue, 1);
+            item = (int)gridDim.x + __builtin_amdgcn_readfirstlane(t);
+        }
     }
     clk_end(P.clk, clk0);
-    osd_small_queue_reset(P.queue);
 }
 
 int host_gf2_rank(const qldpc_graph *g);
 
+// the ticket counter of the one-wave kernels: a buffer of its own on the handle, zeroed when it is created
+int osd_small_queue(const qldpc_graph *g, int **queue) {
+    const bool fresh = g->ws_squeue.p == nullptr;
+    int rc = g->ws_squeue.ensure(16);
+    if (rc != QLDPC_OK) return rc;
+    if (fresh) QLDPC_HIP_TRY(hipMemset(g->ws_squeue.p, 0, 16));
+    *queue = g->ws_squeue.as<int>();
+    return QLDPC_OK;
+}
+
 // handled = true when the matrix is small enough for this kernel (callers hold g->mu)
 int osd0_small_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, bool &handled) {
+                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled) {
     handled = false;
     if (g->m > 128 || g->n > 1024 || g->m < 1 || g->n < 1) return QLDPC_OK;
     OsdSmallArgs P;
@@ -242,10 +246,9 @@ int osd0_small_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t
     P.list = d_list; P.count = d_count; P.synd = d_synd; P.llr = d_llr; P.hard = d_hard; P.ordering = d_ordering; P.solution = d_solution;
     P.clk = g->clk_probe;
     int rc;
-    const bool fresh = g->ws_squeue.p == nullptr;
-    if ((rc = g->ws_squeue.ensure(16)) != QLDPC_OK) return rc;
-    if (fresh) QLDPC_HIP_TRY(hipMemset(g->ws_squeue.p, 0, 16));         // once per graph handle; the kernels leave the queue zeroed (osd_small_queue_reset)
-    P.queue = g->ws_squeue.as<int>();
+    if ((rc = osd_small_queue(g, &P.queue)) != QLDPC_OK) return rc;
+    // the ticket counter must be zero: a caller that zeroes it again after its launches (a Monte-Carlo plan's judge kernel) saves the enqueue here
+    if (!(flags & QLDPC_FLAG_INTERNAL_OSD_QUEUE_CLEAN)) QLDPC_HIP_TRY(hipMemsetAsync(P.queue, 0, 4, stream));
     const size_t lds = (size_t)g->m * (P.nw + 1) * 8 + (size_t)g->n * 8 + (size_t)g->n * 2 + (size_t)g->m * 2 + 16;
     const size_t lds_reg = (size_t)g->n * 8 + (size_t)g->n * 2 + (size_t)g->m * 2 + 16;
     switch (P.nw) {                                                  // n <= 256: the rows fit registers
