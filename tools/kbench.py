@@ -20,9 +20,12 @@ ap.add_argument("--p", type=float, default=0.005)
 ap.add_argument("--max-iter", type=int, default=50)
 ap.add_argument("--modes", default="fixed,ref")
 ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
+ap.add_argument("--opt", default="", help="qldpc_set_option settings, e.g. regular_own=0")
 ap.add_argument("--build", default="product", help="library build (product / experiments / timers or a .so file name in csrc/)")
 a = ap.parse_args()
 _lib.select_build(a.build)
+for kv in filter(None, a.opt.split(",")):
+    _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 c = load_code(a.code)
 g = _lib.Graph(c["Hx_indptr"], c["Hx_indices"], c["n"])
 for mode in a.modes.split(","):
