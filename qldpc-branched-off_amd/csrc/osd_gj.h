@@ -18,7 +18,7 @@ struct OsdGjArgs {
     int *queue;                    // next list entry to process (zeroed before the launch)
     int32_t *redo_list, *redo_count;   // shots whose right-hand side is outside the column space (count zeroed before the launch)
     unsigned long long *clk, *dbg;
-    int offIdx, offAlive, offRows, offPc, offPr, offR, offBlk, offUsed;
+    int offIdx, offAlive, offRows, offPc, offPr, offR, offBlk, offUsed, offTl;
 };
 
 int host_gf2_rank(const qldpc_graph *g);

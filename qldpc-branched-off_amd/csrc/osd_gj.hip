@@ -45,6 +45,8 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
     int *bcolb = blk + 4, *oppb = bcolb + 2 * kGjBlock;                   // bcolb [2][16]: the block's columns (positions in the chunk), double-buffered; oppb [2][16]: pivot rows, by block parity
     uint32_t *selb = reinterpret_cast<uint32_t *>(oppb + 2 * kGjBlock);   // [16] pending operations a column of the block still needs
     int *s_item = reinterpret_cast<int *>(selb + kGjBlock), *sbar = s_item + 1, *nbb = s_item + 2;      // sbar: arrivals at the barrier of the waves 1 .. 15; nbb [2]: block sizes
+    int *tcnt = s_item + 4;                                               // rows the pending block touches (length of tlist)
+    uint32_t *tlist = reinterpret_cast<uint32_t *>(lds + P.offTl);        // [m + 2] row | selector << 16
     uint16_t *ordw = P.ordws + (size_t)blockIdx.x * n;
     const int brow = m + 1;
     auto uix = [&](int q, int w) -> int { return W16 ? q * 16 + (w ^ ((q >> 3) & 14)) : q * mw + w; };      // (uswz, osd_common.h)
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
             const int w = tid & 15;
             usedw[tid] = (w >= mw) ? ~0ull : ((w == mw - 1 && (m & 63)) ? (~0ull << (m & 63)) : 0ull);
         }
-        if (tid == 0) *sbar = 0;
+        if (tid == 0) { *sbar = 0; *tcnt = 0; }
         if (tid < 16) selb[tid] = 0u;
         __syncthreads();
         for (int r = tid; r < m; r += T) {
@@ -266,13 +268,65 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                     const int ppv = ppvPrev;
                     const unsigned long long *Cp = Cb + 16 * cprev * mw;
                     if (W16) {
-                        // rows go to threads as q = 16 * lane + (v + lane) % 16, v = 0 .. 15 (conflict-free 16-byte row accesses under the pair swizzle);
-                        // waves 1 .. 15 stand for v = 0 .. 14, wave 1 then takes v = 15
-                        for (int v = wave - 1; v < 16; v += 15) {
-                            const int q = ((tid & 63) << 4) + ((v + tid) & 15);
+                        // Round 4: SPARSE row updates.  Only ~230 of the 1010 (row, pending block) pairs change anything (a row tests 16 bits, 3.5 % are
+                        // set), so a row first only TESTS -- it reads the dwords that hold its 16 tested bits, not its 128 bytes -- and a row with a set
+                        // bit goes on a list; behind a barrier of the 15 waves the listed rows are updated by 16 lanes each (lane = word: the XOR of the
+                        // selected masks, one read-modify-write of the row's word).  The round-3 form read every row into 32 registers, took the tested
+                        // dwords out with wave-uniform register indices (s_set_gpr_idx mode switches: 1890 of 4570 cycles per pass) and applied the
+                        // visited masks under lane masks: ~9 k cycles per block on the busiest wave, as long as the pivot chain beside it.
+                        const int lane = tid & 63;
+                        int pk[16];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) pk[k] = __builtin_amdgcn_readlane(ppv, k);
+                        for (int v = wave - 1; v < 16; v += 15) {            // waves 1 .. 15 stand for the row groups v = 0 .. 14, wave 1 also takes v = 15
+                            const int q = (lane << 4) + ((v + lane) & 15);
                             const bool act = (q < m + 2) && (q != m);
-                            gj_rows_apply<W16>(U, Cp, act ? q : m, mw, pend, ppv, tid & 63, c_gat);
+                            const int qq = act ? q : m;
+                            const uint32_t *row32 = reinterpret_cast<const uint32_t *>(U + qq * 16);
+                            const int sz = (qq >> 3) & 14;
+                            uint32_t dw[16];
+#pragma unroll
+                            for (int k = 0; k < 16; k++) {                   // (pivot rows of operations that do not exist are 0: a harmless read)
+                                const int d = pk[k] >> 5;
+                                dw[k] = row32[2 * ((d >> 1) ^ sz) + (d & 1)];
+                            }
+                            uint32_t sel = 0u;
+#pragma unroll
+                            for (int k = 0; k < 16; k++) sel |= ((dw[k] >> (pk[k] & 31)) & 1u) << k;
+                            sel &= pend;
+                            const bool hit = act && sel != 0u;
+                            const unsigned long long hm = __ballot(hit);
+#ifdef QLDPC_OSD_TIMERS
+                            c_gat += (unsigned long long)__builtin_popcount(hit ? sel : 0u);
+#endif
+                            if (hm != 0ull) {
+                                const int first = __builtin_ctzll(hm);
+                                int base = 0;
+                                if (lane == first) base = atomicAdd(tcnt, __builtin_popcountll(hm));
+                                base = __builtin_amdgcn_readlane(base, first);
+                                if (hit) tlist[base + __builtin_popcountll(hm & ((1ull << lane) - 1ull))] = (uint32_t)q | (sel << 16);
+                            }
                             if (wave != 1) break;
+                        }
+                        // every row has been tested on the OLD state: now the updates may land (a barrier of the waves 1 .. 15)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) atomicAdd(sbar, 1);
+                        sbar_target += (T >> 6) - 1;
+                        for (int spin = 0; *reinterpret_cast<volatile int *>(sbar) < sbar_target && spin < (1 << 22); spin++) __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const int nt = *reinterpret_cast<volatile int *>(tcnt);
+                        const int l16 = lane & 15;
+                        for (int e = (wave - 1) * 4 + (lane >> 4); e < nt; e += 4 * ((T >> 6) - 1)) {
+                            const uint32_t ent = reinterpret_cast<volatile uint32_t *>(tlist)[e];
+                            const int q = (int)(ent & 0xFFFFu);
+                            uint32_t sel = ent >> 16;
+                            unsigned long long acc = 0ull;
+                            while (sel != 0u) {
+                                const int k = __builtin_ctz(sel);
+                                sel &= sel - 1u;
+                                acc ^= Cp[k * 16 + l16];
+                            }
+                            U[uix(q, l16)] ^= acc;
                         }
                     } else {
                         for (int qb = 0; qb < m + 2; qb += T - 64) {
@@ -299,6 +353,7 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                 if (wave == 1) collect_block(bi ^ 1);                        // the next block's columns, behind the test (collecting before it, while wave 1
                                                                              // waits for the later waves' rows, lets 7 % more dependent columns into the blocks)
                 __syncthreads();
+                if (tid == 64) *tcnt = 0;                                    // (the next appends come behind the barrier of phase (B))
                 bi ^= 1;
                 pend = (uint32_t)blk[1];                                     // columns of the block that pivoted: its operations are pending now
                 const int anydep = blk[2];
@@ -376,6 +431,7 @@ int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d
     P.offR = (int)off; off += (size_t)3 * kGjBlock * P.mw * 8;
     P.offUsed = (int)off; off += 32 * 8;
     P.offBlk = (int)off; off += (4 + 5 * kGjBlock + 8) * 4;
+    P.offTl = (int)off; off += (size_t)round_up((int64_t)(g->m + 2) * 4, 16);
     const size_t lds = off + 16;
     if (lds > 160 * 1024) return QLDPC_OK;
     if (g->gf2_rank < 0) g->gf2_rank = host_gf2_rank(g);      // callers hold g->mu
