@@ -24,6 +24,10 @@ struct OsdGjArgs {
 int host_gf2_rank(const qldpc_graph *g);
 
 constexpr int kGjBlock = 16;
+#ifndef QLDPC_GJ_DENSELANES
+#define QLDPC_GJ_DENSELANES 40
+#endif
+constexpr int kGjDenseLanes = QLDPC_GJ_DENSELANES;    // rows of a wave that must change for the wave to update them in place instead of listing them
 #ifndef QLDPC_GJ_KILLWINDOW
 #define QLDPC_GJ_KILLWINDOW 240
 #endif

@@ -268,12 +268,14 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
                     const int ppv = ppvPrev;
                     const unsigned long long *Cp = Cb + 16 * cprev * mw;
                     if (W16) {
-                        // Round 4: SPARSE row updates.  Only ~230 of the 1010 (row, pending block) pairs change anything (a row tests 16 bits, 3.5 % are
-                        // set), so a row first only TESTS -- it reads the dwords that hold its 16 tested bits, not its 128 bytes -- and a row with a set
-                        // bit goes on a list; behind a barrier of the 15 waves the listed rows are updated by 16 lanes each (lane = word: the XOR of the
-                        // selected masks, one read-modify-write of the row's word).  The round-3 form read every row into 32 registers, took the tested
-                        // dwords out with wave-uniform register indices (s_set_gpr_idx mode switches: 1890 of 4570 cycles per pass) and applied the
-                        // visited masks under lane masks: ~9 k cycles per block on the busiest wave, as long as the pivot chain beside it.
+                        // Round 4: a row first only TESTS -- it reads the dwords that hold its 16 tested bits, not its 128 bytes (the round-3 form read every
+                        // row into 32 registers and took the tested dwords out with wave-uniform register indices: s_set_gpr_idx mode switches, 1890 of the
+                        // 4570 cycles of a pass).  How many rows a block touches swings over a shot: next to none while U is still close to the identity
+                        // (3.5 % of all (row, operation) pairs over a shot), about every row near the end, when the reduced columns are dense.  So per wave:
+                        //   * few rows of the wave hit (< kGjDenseLanes): they go on a list; behind a barrier of the workers the listed rows are updated by
+                        //     16 lanes each (lane = word: XOR of the selected masks, one read-modify-write of the row's word);
+                        //   * many hit: every lane updates its own row on the spot (eight 16-byte reads, the visited masks under lane masks, one write-back)
+                        //     -- an update touches nobody else's row, so it need not wait for the other rows' tests.
                         const int lane = tid & 63;
                         int pk[16];
 #pragma unroll
@@ -299,7 +301,27 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
 #ifdef QLDPC_OSD_TIMERS
                             c_gat += (unsigned long long)__builtin_popcount(hit ? sel : 0u);
 #endif
-                            if (hm != 0ull) {
+                            if (__builtin_popcountll(hm) >= kGjDenseLanes) {
+                                uint4 *Uq = reinterpret_cast<uint4 *>(U + qq * 16);
+                                const int sz4 = (qq >> 4) & 7;
+                                uint4 row[8];
+#pragma unroll
+                                for (int w = 0; w < 8; w++) row[w] = Uq[w ^ sz4];
+#pragma unroll
+                                for (int k = 0; k < 16; k++) {
+                                    const bool mine = hit && ((sel >> k) & 1u);
+                                    if (__ballot(mine) == 0ull) continue;             // nobody in the wave: scalar skip
+                                    if (mine) {
+                                        const uint4 *mk4 = reinterpret_cast<const uint4 *>(Cp + k * 16);
+#pragma unroll
+                                        for (int w = 0; w < 8; w++) { const uint4 t = mk4[w]; row[w].x ^= t.x; row[w].y ^= t.y; row[w].z ^= t.z; row[w].w ^= t.w; }
+                                    }
+                                }
+                                if (hit) {
+#pragma unroll
+                                    for (int w = 0; w < 8; w++) Uq[w ^ sz4] = row[w];
+                                }
+                            } else if (hm != 0ull) {
                                 const int first = __builtin_ctzll(hm);
                                 int base = 0;
                                 if (lane == first) base = atomicAdd(tcnt, __builtin_popcountll(hm));
