@@ -48,12 +48,16 @@ struct Wg2Args {
     const int8_t *synd; const double *alpha;
     double clip;
     int8_t *out_err; double *out_llr; uint8_t *out_conv; int32_t *out_iter;
-    int offST, offSI, offEL, offF, offCH;
+    int offEL, offF, offCH;
     unsigned long long *clk, *dbg;
     int *queue;
 };
 
 constexpr int kWg2Chunks = 5;      // 8 edges each: row degree <= 40
+// LDS layout: the check states come first at FIXED offsets (m <= 1024), so that their addresses are an immediate offset of the LDS instruction and the
+// state address of an edge is two instructions from its 16-bit list entry: (alpha*min1, alpha*min2) pairs [m + 1] at 0, sign words [m + 1] at kWg2OffSI,
+// then the posteriors V [n] at kWg2OffV, the edge list, the flags and the chunk records
+constexpr int kWg2OffSI = 16 * 1025, kWg2OffV = kWg2OffSI + 8 * 1025 + 8;
 
 __device__ __forceinline__ double w2min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double w2min_s(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }
@@ -146,7 +150,7 @@ __device__ __forceinline__ void wg2_row(const uint32_t (&idx)[4 * kWg2Chunks], c
 // the D edges of one column, every lane of the wave has exactly D: entries, then the three words of each check state, then the sum in
 // ascending check order (kernels.py:316).  ST64: the check states as 64-bit words, three per row slot (P1, P2, sign word).
 template <int D>
-__device__ __forceinline__ double wg2_col(const uint16_t *__restrict__ EL, const int (&eoff)[8], int c, const unsigned char *__restrict__ PPb, const unsigned char *__restrict__ SIb) {
+__device__ __forceinline__ double wg2_col(const uint16_t *__restrict__ EL, const int (&eoff)[8], int c, const unsigned char *__restrict__ lds0) {
     uint32_t e[D];
     double2 pp[D];
     unsigned long long si[D];
@@ -154,8 +158,9 @@ __device__ __forceinline__ double wg2_col(const uint16_t *__restrict__ EL, const
     for (int u = 0; u < D; u++) e[u] = EL[eoff[u] + c];
 #pragma unroll
     for (int u = 0; u < D; u++) {                                                            // row slot = e >> 6: byte offsets 16 * slot and 8 * slot
-        pp[u] = *reinterpret_cast<const double2 *>(PPb + ((e[u] >> 2) & 0xFFF0u));
-        si[u] = *reinterpret_cast<const unsigned long long *>(SIb + ((e[u] >> 3) & 0xFFF8u));
+        const uint32_t a = (e[u] >> 2) & 0x3FF0u;
+        pp[u] = *reinterpret_cast<const double2 *>(lds0 + a);
+        si[u] = *reinterpret_cast<const unsigned long long *>(lds0 + kWg2OffSI + (a >> 1));
     }
     double s = 0.0;                                                                          // kernels.py:279
 #pragma unroll
@@ -167,9 +172,10 @@ __device__ __forceinline__ double wg2_col(const uint16_t *__restrict__ EL, const
     return s;
 }
 
-__device__ __forceinline__ double wg2_edge(uint32_t e, const unsigned char *__restrict__ PPb, const unsigned char *__restrict__ SIb) {
-    const double2 pp = *reinterpret_cast<const double2 *>(PPb + ((e >> 2) & 0xFFF0u));
-    const unsigned long long w = *reinterpret_cast<const unsigned long long *>(SIb + ((e >> 3) & 0xFFF8u));
+__device__ __forceinline__ double wg2_edge(uint32_t e, const unsigned char *__restrict__ lds0) {
+    const uint32_t a = (e >> 2) & 0x3FF0u;
+    const double2 pp = *reinterpret_cast<const double2 *>(lds0 + a);
+    const unsigned long long w = *reinterpret_cast<const unsigned long long *>(lds0 + kWg2OffSI + (a >> 1));
     const uint32_t k = e & 63u;
     return signed_mag((k == ((uint32_t)w & 255u)) ? pp.y : pp.x, (uint32_t)((w << k) >> 32));
 }
@@ -177,10 +183,9 @@ __device__ __forceinline__ double wg2_edge(uint32_t e, const unsigned char *__re
 template <bool NANSEL>
 __global__ __launch_bounds__(1024) void minsum_wg2_kernel(Wg2Args A) {
     extern __shared__ unsigned char lds[];
-    double *V = reinterpret_cast<double *>(lds);                                             // [n] by column slot
-    double2 *PP = reinterpret_cast<double2 *>(lds + A.offST);                                // [m + 1] (alpha*min1, alpha*min2), unsigned
-    unsigned long long *SI = reinterpret_cast<unsigned long long *>(lds + A.offSI);          // [m + 1] sign word | argmin
-    const unsigned char *PPb = lds + A.offST, *SIb = lds + A.offSI;
+    double *V = reinterpret_cast<double *>(lds + kWg2OffV);                                  // [n] by column slot
+    double2 *PP = reinterpret_cast<double2 *>(lds);                                          // [m + 1] (alpha*min1, alpha*min2), unsigned
+    unsigned long long *SI = reinterpret_cast<unsigned long long *>(lds + kWg2OffSI);        // [m + 1] sign word | argmin
     uint16_t *EL = reinterpret_cast<uint16_t *>(lds + A.offEL);                              // [nnz]
     int *unsat = reinterpret_cast<int *>(lds + A.offF);
     Wg2Chunk *CH = reinterpret_cast<Wg2Chunk *>(lds + A.offCH);                              // [ceil(n / 64)]
@@ -272,29 +277,33 @@ __global__ __launch_bounds__(1024) void minsum_wg2_kernel(Wg2Args A) {
             if (tid == 0) unsat[(it + 1) & 1] = 0;
             t_frz += OSD_CLOCK() - tq; tq = OSD_CLOCK(); n_it++;
             // variable pass: values_it
+            uint4 rec = reinterpret_cast<const uint4 *>(CH)[tid >> 6];                       // the wave's degree and prior of a pass: ONE broadcast read, a pass ahead
             for (int c0 = tid & ~63; c0 < n; c0 += T) {
                 const int c = c0 + (tid & 63);
-                const Wg2Chunk ci = CH[c0 >> 6];                                             // one broadcast read per pass: the wave's degree and prior
-                if (__builtin_amdgcn_readfirstlane(ci.pure)) {
+                const uint4 cur = rec;
+                if (c0 + T < n) rec = reinterpret_cast<const uint4 *>(CH)[(c0 + T) >> 6];
+                struct { double prior; int deg; } ci;
+                ci.prior = __hiloint2double((int)cur.y, (int)cur.x); ci.deg = (int)cur.z;
+                if (__builtin_amdgcn_readfirstlane((int)cur.w)) {
                     double s;
                     const int dgu = __builtin_amdgcn_readfirstlane(ci.deg);
                     switch (dgu) {
                         case 0: s = 0.0; break;
-                        case 2: s = wg2_col<2>(EL, eoff, c, PPb, SIb); break;
-                        case 3: s = wg2_col<3>(EL, eoff, c, PPb, SIb); break;
-                        case 4: s = wg2_col<4>(EL, eoff, c, PPb, SIb); break;
-                        case 5: s = wg2_col<5>(EL, eoff, c, PPb, SIb); break;
-                        case 6: s = wg2_col<6>(EL, eoff, c, PPb, SIb); break;
+                        case 2: s = wg2_col<2>(EL, eoff, c, lds); break;
+                        case 3: s = wg2_col<3>(EL, eoff, c, lds); break;
+                        case 4: s = wg2_col<4>(EL, eoff, c, lds); break;
+                        case 5: s = wg2_col<5>(EL, eoff, c, lds); break;
+                        case 6: s = wg2_col<6>(EL, eoff, c, lds); break;
                         default: {                                                           // degree 1, 7, 8
                             s = 0.0;
-                            for (int d = 0; d < dgu; d++) s += wg2_edge(EL[eoff[d] + c], PPb, SIb);
+                            for (int d = 0; d < dgu; d++) s += wg2_edge(EL[eoff[d] + c], lds);
                         }
                     }
                     V[c] = s + ci.prior;                                                     // kernels.py:320
                 } else if (c < n) {                                                          // a chunk that mixes classes (or the ragged last one): per-lane degree and prior
                     const int dj = A.degc[c];
                     double s = 0.0;
-                    for (int d = 0; d < dj; d++) s += wg2_edge(EL[eoff[d] + c], PPb, SIb);
+                    for (int d = 0; d < dj; d++) s += wg2_edge(EL[eoff[d] + c], lds);
                     V[c] = s + A.prior_s[c];
                 }
             }
@@ -321,7 +330,7 @@ struct Wg2Prep {
     int nan_deg1_only = 1, has_deg1 = 0;
     int eoff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t lds = 0;
-    int offST = 0, offSI = 0, offEL = 0, offF = 0, offCH = 0;
+    int offEL = 0, offF = 0, offCH = 0;
     DevBuf row_of_slot, degr, ell_cs, el, chunks, prior_s, degc, slot_of_col;
     ~Wg2Prep() { for (DevBuf *b : {&row_of_slot, &degr, &ell_cs, &el, &chunks, &prior_s, &degc, &slot_of_col}) b->release(); }
 };
@@ -343,9 +352,7 @@ static int wg2_build(const qldpc_graph *g, const double *prior, Wg2Prep &P) {
     P.prior.assign(prior, prior + n);
     P.usable = false;
     if (m < 1 || n < 1 || m > 1024 || n >= 65536 || g->max_row_deg > 8 * kWg2Chunks || g->max_col_deg > 8 || nnz < 1) return QLDPC_OK;
-    P.offST = (int)round_up((int64_t)n * 8, 16);
-    P.offSI = P.offST + (m + 1) * 16;
-    P.offEL = P.offSI + (m + 1) * 8;
+    P.offEL = (int)round_up((int64_t)kWg2OffV + (int64_t)n * 8, 16);
     P.offF = (int)round_up((int64_t)P.offEL + ((int64_t)nnz + 1) / 2 * 4, 16);
     P.offCH = P.offF + 32;
     P.lds = (size_t)P.offCH + (size_t)((n + 63) / 64) * sizeof(Wg2Chunk);
@@ -448,7 +455,7 @@ int minsum_wg2_launch(const qldpc_graph *g, const Wg2Prep *P, int64_t B, const i
     A.chunks = P->chunks.as<Wg2Chunk>(); A.prior_s = P->prior_s.as<double>(); A.degc = P->degc.as<uint8_t>(); A.slot_of_col = P->slot_of_col.as<int32_t>();
     A.B = B; A.synd = d_synd; A.alpha = d_alpha; A.clip = clip;
     A.out_err = d_err; A.out_llr = d_llr; A.out_conv = d_conv; A.out_iter = d_iter;
-    A.offST = P->offST; A.offSI = P->offSI; A.offEL = P->offEL; A.offF = P->offF; A.offCH = P->offCH;
+    A.offEL = P->offEL; A.offF = P->offF; A.offCH = P->offCH;
     const unsigned grid = (unsigned)std::min<int64_t>(B, 256 * 2);
     int rc = g->ws_queue.ensure(16);
     if (rc != QLDPC_OK) return rc;
