@@ -195,19 +195,19 @@ __global__ __launch_bounds__(1024) void osd0_kernel(OsdArgs P) {
 }
 
 int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
-                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
+                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled, OsdJudge *judge);
 
 static int osd0_global_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
                               const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream);
 
 // callers hold g->mu; the graph's device workspaces are handed over in stream order (common.h)
 int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
-                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream) {
+                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, OsdJudge *judge) {
     if (g->m == 0 || g->n == 0) return QLDPC_OK;
     int rc = g->ws_acquire(stream);                 // (a no-op for a caller that already holds the workspaces on this stream)
     if (rc != QLDPC_OK) return rc;
     bool handled = false;           // LDS-resident kernels for m <= 4096; the global-memory kernel is the general fallback
-    rc = osd0_lds_launch(g, d_list, d_count, max_listed, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
+    rc = osd0_lds_launch(g, d_list, d_count, max_listed, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled, judge);
     if (rc == QLDPC_OK && !handled) rc = osd0_global_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, stream);
     const int rel = g->ws_release(stream);          // always: a failing call may have enqueued launches the next stream has to wait for
     return rc != QLDPC_OK ? rc : rel;
@@ -1097,7 +1097,7 @@ int ensure_col_rows(const qldpc_graph *g) {
 }
 
 int osd0_small_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled);
+                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled, OsdJudge *judge);
 
 // rank of H over GF(2) (host, once per graph): the sweep above can stop as soon as this many pivots exist
 int host_gf2_rank(const qldpc_graph *g) {
@@ -1151,12 +1151,12 @@ int osd0_gjg_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
                     const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, hipStream_t stream, size_t ws_offset, bool &handled);
 
 int osd0_lds_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
-                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled) {
+                    const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled, OsdJudge *judge) {
     OsdLdsArgs P;
     size_t lds = 0;
     handled = false;
     if (!(flags & (QLDPC_FLAG_OSD_LDS | QLDPC_FLAG_OSD_UG | QLDPC_FLAG_OSD_GLOBAL))) {      // small matrices: the literal elimination, one wave per shot
-        const int rcs = osd0_small_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled);
+        const int rcs = osd0_small_launch(g, d_list, d_count, d_synd, d_llr, d_hard, d_ordering, d_solution, flags, stream, handled, judge);
         if (rcs != QLDPC_OK || handled) return rcs;
     }
 #ifndef QLDPC_EXPERIMENTS

@@ -362,10 +362,13 @@ QLDPC_EXPORT int qldpc_cc_plan_run(qldpc_cc_plan *P, uint64_t seed, int64_t shot
                 // stream) zeroes it for the next piece and the launch skips its memset
                 int *osd_q = nullptr;
                 if (go->ws_private && (rc = osd_small_queue(go, &osd_q)) != QLDPC_OK) return rc;
+                // (on such a lane the one-wave OSD-0 kernels of small matrices also take the judge over: two enqueues per piece instead of three)
+                OsdJudge J{b_err.as<int8_t>(), P->d_Lmask.as<uint64_t>(), P->d_tally.as<unsigned long long>(), b_count.as<int32_t>(), B, false};
                 if ((rc = osd0_listed_launch(go, b_list.as<int32_t>(), b_count.as<int32_t>(), B, b_synd.as<int8_t>(), b_llr.as<double>(),
-                                             b_dec.as<int8_t>(), nullptr, b_dec.as<int8_t>(), (P->flags & QLDPC_FLAG_PUBLIC_MASK) | (osd_q ? QLDPC_FLAG_INTERNAL_OSD_QUEUE_CLEAN : 0), ts)) != QLDPC_OK)
+                                             b_dec.as<int8_t>(), nullptr, b_dec.as<int8_t>(), (P->flags & QLDPC_FLAG_PUBLIC_MASK) | (osd_q ? QLDPC_FLAG_INTERNAL_OSD_QUEUE_CLEAN : 0), ts,
+                                             osd_q ? &J : nullptr)) != QLDPC_OK)
                     return rc;
-                if ((rc = judge_failed_launch(g, b_count.as<int32_t>(), true, osd_q, P->d_Lmask.as<uint64_t>(), b_err.as<int8_t>(), b_synd.as<int8_t>(),
+                if (!J.fused && (rc = judge_failed_launch(g, b_count.as<int32_t>(), true, osd_q, P->d_Lmask.as<uint64_t>(), b_err.as<int8_t>(), b_synd.as<int8_t>(),
                                               b_dec.as<int8_t>(), P->d_tally.as<unsigned long long>(), ts)) != QLDPC_OK)
                     return rc;
                 if (P->side) { QLDPC_HIP_TRY(hipEventRecord(Ln->tail, ts)); Ln->tail_pending = true; }

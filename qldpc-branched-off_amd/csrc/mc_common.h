@@ -62,7 +62,10 @@ int gf2_spmv_launch(const qldpc_graph *g, int64_t B, const int8_t *d_vec, int8_t
 
 // OSD-0 on the shots listed in d_list[0 .. *d_count) (device-resident count: no host sync).  d_ordering may be NULL
 // (stable ascending |llr|); otherwise int32[B][n] indexed by shot.  solution may alias hard.  max_listed: an upper bound of *d_count.
+// judge: a caller's per-record judge (logical failure / syndrome check of the solution against the true error, tallied) that the launch MAY take over --
+// the one-wave kernels of small matrices do (fused = true on return); the caller launches its own judge kernel when fused stays false
+struct OsdJudge { const int8_t *err; const uint64_t *Lmask; unsigned long long *tally; int32_t *count; int64_t max_listed; bool fused; };
 int osd0_listed_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, int64_t max_listed, const int8_t *d_synd, const double *d_llr,
-                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream);
+                       const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, OsdJudge *judge = nullptr);
 
 }  // namespace qldpc

@@ -24,7 +24,40 @@ struct OsdSmallArgs {
     int8_t *solution;
     int *queue;
     unsigned long long *clk;
+    // fused judge (a Monte-Carlo piece on a lane of its own, csrc/mc.hip): the wave that solved a record also compares it with the true error
+    // (logical failure, engine.py:99-100; syndrome check) and the last workgroup zeroes the piece's counters -- one launch instead of two
+    const int8_t *jerr; const uint64_t *jLmask; unsigned long long *jtally; int32_t *jcount;
 };
+
+// judge of one solved record by the wave that solved it: dsol [n] (LDS) holds the solution bits
+__device__ __forceinline__ void osd_small_judge(const OsdSmallArgs &P, int64_t shot, const uint8_t *dsol, int lane) {
+    const int m = P.m, n = P.n;
+    const int8_t *err = P.jerr + shot * n, *synd = P.synd + shot * m;
+    unsigned long long lm = 0ull;
+    for (int j = lane; j < n; j += 64)
+        if ((err[j] ^ dsol[j]) & 1) lm ^= P.jLmask[j];
+    int bad = 0;
+    for (int i = lane; i < m; i += 64) {
+        int par = 0;
+        for (int e = P.indptr[i]; e < P.indptr[i + 1]; e++) par ^= dsol[P.indices[e]];
+        bad |= (par ^ synd[i]) & 1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lm ^= __shfl_xor(lm, off, 64); bad |= __shfl_xor(bad, off, 64); }
+    if (lane == 0) {
+        if (lm) { atomicAdd(&P.jtally[QLDPC_TALLY_Z_ERR], 1ull); atomicAdd(&P.jtally[QLDPC_TALLY_TOTAL_ERR], 1ull); }
+        if (bad) atomicAdd(&P.jtally[QLDPC_TALLY_UNSAT_Z], 1ull);
+    }
+}
+
+// end of a fused launch: the OSD count of the piece, and the LAST workgroup to get here zeroes the piece's counters and the ticket counter (every
+// workgroup read `total` before it can be counted)
+__device__ __forceinline__ void osd_small_judge_finish(const OsdSmallArgs &P, int total, int lane) {
+    if (lane != 0) return;
+    if (blockIdx.x == 0 && total) atomicAdd(&P.jtally[QLDPC_TALLY_OSD_Z], (unsigned long long)total);
+    __threadfence();
+    if (atomicAdd(&P.jcount[3], 1) == (int)gridDim.x - 1) { P.jcount[0] = 0; P.jcount[2] = 0; P.jcount[3] = 0; *P.queue = 0; __threadfence(); }
+}
 
 // Work hand-out: workgroup b takes list entry b without asking, further entries come from a ticket counter (tickets start at gridDim.x).  A launch over
 // a handful of failures -- what a Monte-Carlo piece of a few thousand shots produces -- then issues no atomic at all: 2048 workgroups drawing a ticket
@@ -36,6 +69,7 @@ __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
     unsigned long long *keys = A + (size_t)m * rs;                                          // [n]
     uint16_t *ord = reinterpret_cast<uint16_t *>(keys + n);                                 // [n] columns in reliability order
     uint16_t *pivcol = ord + n;                                                             // [m] column of the pivot at position t
+    uint8_t *dsol = reinterpret_cast<uint8_t *>(pivcol + m);                                // [n] solution bits (fused judge only)
     const ClkStamp clk0 = clk_begin(P.clk);
     const int total = *P.count;
     for (int item = blockIdx.x; item < total;) {
@@ -100,12 +134,16 @@ __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
             __builtin_amdgcn_wave_barrier();
         }
         // ---- back-fill (osd.py:19-25): e[pivot col] = reduced rhs at the pivot row; solution = (hard + e) % 2 ----
+        if (P.jerr) for (int j = lane; j < n; j += 64) dsol[j] = (uint8_t)(hard[j] & 1);
         if (sol != hard) for (int j = lane; j < n; j += 64) sol[j] = hard[j];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         for (int t = lane; t < rank; t += 64) {
             const int j = pivcol[t];
-            sol[j] = (int8_t)((hard[j] ^ (int8_t)(A[(size_t)t * rs + nw] & 1ull)) & 1);
+            const int8_t v = (int8_t)((hard[j] ^ (int8_t)(A[(size_t)t * rs + nw] & 1ull)) & 1);
+            sol[j] = v;
+            if (P.jerr) dsol[j] = (uint8_t)v;
         }
+        if (P.jerr) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); osd_small_judge(P, shot, dsol, lane); }
         {   // next entry: a ticket (the first gridDim.x entries were handed out by workgroup index)
             int t = 0;
             if (lane == 0) t = atomicAdd(P.queue, 1);
@@ -113,6 +151,7 @@ __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
         }
     }
     clk_end(P.clk, clk0);
+    if (P.jerr) osd_small_judge_finish(P, total, lane);
 }
 
 // The same with the matrix in REGISTERS (n <= 64 NW columns, NW <= 4): lane r holds rows r and r + 64 (NW matrix words + the rhs each).  The LDS
@@ -137,6 +176,7 @@ __global__ __launch_bounds__(64) void osd0_small_reg_kernel(OsdSmallArgs P) {
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(lds);                 // [n]
     uint16_t *ord = reinterpret_cast<uint16_t *>(keys + n);                                 // [n] columns in reliability order
     uint16_t *pivcol = ord + n;                                                             // [m] column of the pivot at position t
+    uint8_t *dsol = reinterpret_cast<uint8_t *>(pivcol + m);                                // [n] solution bits (fused judge only)
     const ClkStamp clk0 = clk_begin(P.clk);
     const int total = *P.count;
     const int r0 = lane, r1 = lane + 64;
@@ -207,11 +247,13 @@ __global__ __launch_bounds__(64) void osd0_small_reg_kernel(OsdSmallArgs P) {
         }
         __builtin_amdgcn_wave_barrier();
         // back-fill (osd.py:19-25): e[pivot col] = reduced rhs of the row at the pivot's position; solution = (hard + e) % 2
+        if (P.jerr) for (int jj = lane; jj < n; jj += 64) dsol[jj] = (uint8_t)(hard[jj] & 1);
         if (sol != hard) for (int jj = lane; jj < n; jj += 64) sol[jj] = hard[jj];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (pos0 < rank) { const int jj = pivcol[pos0]; sol[jj] = (int8_t)((hard[jj] ^ (int8_t)(a[0][NW] & 1ull)) & 1); }
-        if (pos1 < rank) { const int jj = pivcol[pos1]; sol[jj] = (int8_t)((hard[jj] ^ (int8_t)(a[1][NW] & 1ull)) & 1); }
+        if (pos0 < rank) { const int jj = pivcol[pos0]; const int8_t v = (int8_t)((hard[jj] ^ (int8_t)(a[0][NW] & 1ull)) & 1); sol[jj] = v; if (P.jerr) dsol[jj] = (uint8_t)v; }
+        if (pos1 < rank) { const int jj = pivcol[pos1]; const int8_t v = (int8_t)((hard[jj] ^ (int8_t)(a[1][NW] & 1ull)) & 1); sol[jj] = v; if (P.jerr) dsol[jj] = (uint8_t)v; }
         __builtin_amdgcn_wave_barrier();
+        if (P.jerr) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); osd_small_judge(P, shot, dsol, lane); }
         {   // next entry: a ticket (the first gridDim.x entries were handed out by workgroup index)
             int t = 0;
             if (lane == 0) t = atomicAdd(P.queue, 1);
@@ -219,6 +261,7 @@ __global__ __launch_bounds__(64) void osd0_small_reg_kernel(OsdSmallArgs P) {
         }
     }
     clk_end(P.clk, clk0);
+    if (P.jerr) osd_small_judge_finish(P, total, lane);
 }
 
 int host_gf2_rank(const qldpc_graph *g);
@@ -235,7 +278,7 @@ int osd_small_queue(const qldpc_graph *g, int **queue) {
 
 // handled = true when the matrix is small enough for this kernel (callers hold g->mu)
 int osd0_small_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d_count, const int8_t *d_synd, const double *d_llr,
-                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled) {
+                      const int8_t *d_hard, const int32_t *d_ordering, int8_t *d_solution, int flags, hipStream_t stream, bool &handled, OsdJudge *judge) {
     handled = false;
     if (g->m > 128 || g->n > 1024 || g->m < 1 || g->n < 1) return QLDPC_OK;
     OsdSmallArgs P;
@@ -249,14 +292,22 @@ int osd0_small_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t
     if ((rc = osd_small_queue(g, &P.queue)) != QLDPC_OK) return rc;
     // the ticket counter must be zero: a caller that zeroes it again after its launches (a Monte-Carlo plan's judge kernel) saves the enqueue here
     if (!(flags & QLDPC_FLAG_INTERNAL_OSD_QUEUE_CLEAN)) QLDPC_HIP_TRY(hipMemsetAsync(P.queue, 0, 4, stream));
-    const size_t lds = (size_t)g->m * (P.nw + 1) * 8 + (size_t)g->n * 8 + (size_t)g->n * 2 + (size_t)g->m * 2 + 16;
-    const size_t lds_reg = (size_t)g->n * 8 + (size_t)g->n * 2 + (size_t)g->m * 2 + 16;
+    P.jerr = nullptr; P.jLmask = nullptr; P.jtally = nullptr; P.jcount = nullptr;
+    unsigned grid = 2048;
+    if (judge && !d_ordering) {             // the caller's judge rides on this launch (it owns the ticket counter: QLDPC_FLAG_INTERNAL_OSD_QUEUE_CLEAN)
+        P.jerr = judge->err; P.jLmask = judge->Lmask; P.jtally = judge->tally; P.jcount = judge->count;
+        // every workgroup ends on one atomic (the counter reset belongs to the last one): a grid for the piece, not for the worst case of any piece
+        grid = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(32, judge->max_listed / 32));
+        judge->fused = true;
+    }
+    const size_t lds = (size_t)g->m * (P.nw + 1) * 8 + (size_t)g->n * 8 + (size_t)g->n * 2 + (size_t)g->m * 2 + (size_t)g->n + 16;
+    const size_t lds_reg = (size_t)g->n * 8 + (size_t)g->n * 2 + (size_t)g->m * 2 + (size_t)g->n + 16;
     switch (P.nw) {                                                  // n <= 256: the rows fit registers
-        case 1: hipLaunchKernelGGL(osd0_small_reg_kernel<1>, dim3(2048), dim3(64), lds_reg, stream, P); break;
-        case 2: hipLaunchKernelGGL(osd0_small_reg_kernel<2>, dim3(2048), dim3(64), lds_reg, stream, P); break;
-        case 3: hipLaunchKernelGGL(osd0_small_reg_kernel<3>, dim3(2048), dim3(64), lds_reg, stream, P); break;
-        case 4: hipLaunchKernelGGL(osd0_small_reg_kernel<4>, dim3(2048), dim3(64), lds_reg, stream, P); break;
-        default: hipLaunchKernelGGL(osd0_small_kernel, dim3(2048), dim3(64), lds, stream, P);
+        case 1: hipLaunchKernelGGL(osd0_small_reg_kernel<1>, dim3(grid), dim3(64), lds_reg, stream, P); break;
+        case 2: hipLaunchKernelGGL(osd0_small_reg_kernel<2>, dim3(grid), dim3(64), lds_reg, stream, P); break;
+        case 3: hipLaunchKernelGGL(osd0_small_reg_kernel<3>, dim3(grid), dim3(64), lds_reg, stream, P); break;
+        case 4: hipLaunchKernelGGL(osd0_small_reg_kernel<4>, dim3(grid), dim3(64), lds_reg, stream, P); break;
+        default: hipLaunchKernelGGL(osd0_small_kernel, dim3(grid), dim3(64), lds, stream, P);
     }
     QLDPC_HIP_TRY(hipGetLastError());
     handled = true;

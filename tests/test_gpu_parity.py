@@ -123,7 +123,9 @@ def test_circuit_level_golden(Lb, golden, oracle, tag):
         ip, ix = data[f"Hdec{s}_indptr"], data[f"Hdec{s}_indices"]
         m, n = (int(x) for x in data[f"Hdec{s}_shape"])
         graph = L.Graph(ip, ix, n)
-        for fl in for_build(L, (0, L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM)):      # auto = workgroup-per-shot kernel; streaming kernel forced
+        # auto = workgroup-per-shot kernel, LDS-resident form (csrc/minsum_wg2.hip: the prior is known on the host); FLAG_WG_TABLES = the form with its
+        # index tables in HBM / L2 (csrc/minsum_wg.hip, what the *_dev entry points run); streaming kernel forced
+        for fl in for_build(L, (0, L.FLAG_FIXED_ITERS, L.FLAG_WG_TABLES, L.FLAG_WG_TABLES | L.FLAG_FIXED_ITERS, L.FLAG_KERNEL_STREAM)):
             check(decode(L, graph, g[f"{s}_syndromes"], g[f"llrs_{s}"], int(g["max_iter"]), fl), g, s)
         # the generic (any-input) workgroup kernel and the natural row / column order must agree with the lean, degree-sorted default
         for fl in for_build(L, (L.FLAG_WG_GENERIC, L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC | L.FLAG_WG_ROWMAJOR, L.FLAG_WG_EDGE_LANES, L.FLAG_WG_EDGE_LANES | L.FLAG_FIXED_ITERS,
@@ -169,6 +171,40 @@ def test_circuit_level_golden(Lb, golden, oracle, tag):
             hd = (rng2.random(n) < 0.05).astype(np.int8)
             assert np.array_equal(performOSD_enhanced(H, sy, ll, hd, order=0, ordering=np.argsort(np.abs(ll), kind="stable")), oracle.osd0(ip, ix, n, sy, ll, hd)), (tag, s, trial)
             assert np.array_equal(L.osd0_batch(graph, sy[None], ll[None], hd[None])[0], oracle.osd0(ip, ix, n, sy, ll, hd)), (tag, s, trial)
+
+
+@pytest.mark.parametrize("tag", ["circ72", "circ144"])
+def test_workgroup_kernel_lds_resident_form(L, oracle, tag):
+    """The two forms of the workgroup-per-shot decoder -- tables in LDS (csrc/minsum_wg2.hip: host-known prior, column slots by (degree, prior) class) and
+    tables in HBM / L2 (csrc/minsum_wg.hip) -- against the oracle and each other on inputs that take different paths through the first one: the real
+    priors (11 - 15 classes, a few chunks that mix classes), a two-valued prior scattered at random, a uniform prior, a prior of all-distinct values (not
+    eligible: falls back to the table kernel whatever the flag), ragged batches, few and many iterations, the fixed-work mode, and both sectors (HdecX has
+    degree-1 checks: +-inf messages and the NaN -> 0 rule of kernels.py:328)."""
+    from qldpc_amd.data import load_circuit_matrices
+    from qldpc_amd.simulation.engine import prior_llrs
+    d = load_circuit_matrices(tag)
+    rng = np.random.default_rng(23)
+    for sct in "ZX":
+        ip, ix = d[f"Hdec{sct}_indptr"], d[f"Hdec{sct}_indices"]
+        m, n = (int(x) for x in d[f"Hdec{sct}_shape"])
+        graph = L.Graph(ip, ix, n)
+        real = prior_llrs(d[f"channel_probs{sct}"])
+        priors = {"real": real, "two values": np.where(rng.random(n) < 0.3, 2.5, 6.25), "uniform": np.full(n, 4.0),
+                  "all distinct": 3.0 + np.arange(n) * 1e-3, "with a negative class": np.where(rng.random(n) < 0.1, -1.5, real)}
+        for name, pr in priors.items():
+            for B, iters, p_err in ((5, 3, 0.004), (67, 17, 0.006)):
+                E = (rng.random((B, n)) < p_err).astype(np.int8)
+                synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
+                synd[0] = rng.random(m) < 0.4                      # an unrealisable syndrome: never converges
+                ref = oracle.minsum_decode_batch(ip, ix, n, synd, pr, max_iter=iters, threads=0)
+                for fl in (0, L.FLAG_FIXED_ITERS, L.FLAG_WG_TABLES):
+                    got = L.minsum_decode_batch(graph, synd, pr, iters, "dynamical", 1.0, flags=fl)
+                    for x, y, what in zip(got, ref, ("err", "conv", "llr", "iter")):
+                        assert np.array_equal(x, y, equal_nan=(what == "llr")), (tag, sct, name, B, iters, fl, what)
+                got = L.minsum_decode_batch(graph, synd, pr, iters, "alvarado", 0.8, clip_llr=7.5)       # another alpha schedule and clip bound
+                ref2 = oracle.minsum_decode_batch(ip, ix, n, synd, pr, max_iter=iters, alpha=0.8, alpha_mode="alvarado", clip_llr=7.5, threads=0)
+                for x, y in zip(got, ref2):
+                    assert np.array_equal(x, y, equal_nan=True), (tag, sct, name, "alvarado")
 
 
 @pytest.mark.parametrize("kern", ["regular", "generic", "stream"])

@@ -284,7 +284,7 @@ def analyse(src, pattern, loop_pick=None):
 RECORDED = {
     "cc_bb144_fixed": ("minsum_regular.hip", "minsum_regular_kernel<6, 3, false, true, true, true>", None, ["minsum_regular.hip", "minsum_common.h", "minsum_f64.h", "mc_common.h"]),
     "cc_bb144_early_exit": ("mc_first.hip", "mc_first_kernel<8, 6, 3>", None, ["mc_first.hip", "mc_common.h"]),
-    "circ144_bp": ("minsum_wg.hip", "minsum_wg_lean_kernel<true, false, false, true>", "whole", ["minsum_wg.hip", "minsum_common.h"]),
+    "circ144_bp": ("minsum_wg2.hip", "minsum_wg2_kernel<false>", "whole", ["minsum_wg2.hip", "minsum_common.h"]),
     "circ144_osd": ("osd_gj.hip", "osd0_gj_kernel<true>", "whole", ["osd_gj.hip", "osd_gj.h", "osd_common.h"]),
 }
 

@@ -62,8 +62,8 @@ def main():
         f"cc_{wl['code']}_early_exit": (lambda k: "mc_first_kernel" in k, 2, wl["cc_early_exit"]["shots_per_launch"], "shot", ["mc_first.hip", "mc_common.h"]),
         f"cc_{wl['code']}_early_exit_full": (lambda k: (regular_args(k) or [""] * 6)[4:6] == ["true", "false"], 2,
                                              wl["cc_early_exit"]["shots_per_launch"], "shot", regular),
-        f"{wl['circuit']}_bp": (lambda k: "minsum_wg_lean_kernel" in k, 2, (cl["iters_z"] + cl["iters_x"]) / 2.0, "decode_iteration",
-                                ["minsum_wg.hip", "minsum_common.h"]),
+        f"{wl['circuit']}_bp": (lambda k: "minsum_wg2_kernel" in k, 2, (cl["iters_z"] + cl["iters_x"]) / 2.0, "decode_iteration",
+                                ["minsum_wg2.hip", "minsum_common.h"]),
         f"{wl['circuit']}_osd": (lambda k: "osd0_gj_kernel" in k, 2, (cl["osd_z"] + cl["osd_x"]) / 2.0, "osd_shot",
                                  ["osd_gj.hip", "osd_gj.h", "osd_common.h"]),
     }

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU-box pass that produces everything profiles/ carries for a round (run from the repo root through gpurun):
-#   bash tools/profile_round.sh r03a          ->  gpurun_out/<tag>/ : bench JSON (plain and under rocprofv3), kernel stats CSV, PMC passes,
+#   bash tools/profile_round.sh r04a          ->  gpurun_out/<tag>/ : bench JSON (plain and under rocprofv3), kernel stats CSV, PMC passes,
 #                                                  pmc.json + <tag>_pmc.txt, OSD workload counts (diagnostic build), issue-rate table
 # Copy what is to be judged into profiles/ afterwards (tools/profile_collect.py does it).
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT/pmc"
 export TMPDIR=/tmp
@@ -18,7 +18,7 @@ echo "[4] bench (plain)" && timeout -k 10 600 python3 bench.py > "$OUT/bench.jso
 echo "[5] bench under rocprofv3 --kernel-trace --stats" && (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -- python3 "$OLDPWD/bench.py" --no-cpu-baseline > "$OLDPWD/$OUT/bench_under_rocprof.json" 2> "$OLDPWD/$OUT/bench_under_rocprof.err")
 find "$OUT/prof" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
 echo "[6] other configs" && (timeout -k 10 200 python3 bench.py --code bb72 --circuit none --no-cpu-baseline; timeout -k 10 200 python3 bench.py --code bb72 --batch 4096 --steps 200 --circuit none --no-cpu-baseline; timeout -k 10 300 python3 bench.py --code bb288 --p-sweep 0.004,0.005,0.006 --circuit none --no-cpu-baseline;
-  echo "# config 2 as BASELINE quotes it: ONE run() call over 2 097 152 shots with batch = 4096 (tools/kbench_batch.py; granule -1 = the default, 0 = the batch taken literally)";
-  timeout -k 10 200 python3 tools/kbench_batch.py --batches 4096 --granule=-1,0) > "$OUT/other_configs.txt" 2>&1
+  echo "# config 2 as BASELINE quotes it: ONE run() call over 2 097 152 shots with batch = 4096 (tools/kbench_batch.py; granule = min_launch of the plan, 0 = the batch taken literally)";
+  timeout -k 10 200 python3 tools/kbench_batch.py --batches 4096,8192,32768 --granule=0,32768,262144) > "$OUT/other_configs.txt" 2>&1
 rm -rf "$OUT/prof" "$OUT/pmc/sq_a" "$OUT/pmc/sq_b" "$OUT/pmc/sq_c" "$OUT/pmc/fetch" "$OUT/pmc/write" "$OUT/pmc/grbm"
 head -c 1500 "$OUT/bench.json"; echo; tail -5 "$OUT/pmc_summary.txt" | cut -c1-400
