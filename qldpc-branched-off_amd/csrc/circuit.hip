@@ -295,7 +295,7 @@ static int build_signatures(const qldpc_circuit_desc *D, bool xsector, const std
     QLDPC_HIP_TRY(hipMemcpy(dops.p, ops.data(), len * 4, hipMemcpyHostToDevice));
     QLDPC_HIP_TRY(hipMemcpy(dq1.p, q1.data(), len * 4, hipMemcpyHostToDevice));
     QLDPC_HIP_TRY(hipMemcpy(dq2.p, q2.data(), len * 4, hipMemcpyHostToDevice));
-    QLDPC_HIP_TRY(hipMemset(dhist.p, 0, (size_t)nsyn * nl));
+    QLDPC_HIP_TRY(zero_now(dhist.p, (size_t)nsyn * nl));
     const unsigned grid = (unsigned)((nl + 255) / 256);
     if (xsector)
         hipLaunchKernelGGL(fault_signature_kernel<true>, dim3(grid), dim3(256), 0, nullptr, nl, dpos.as<int32_t>(), dafter.as<int8_t>(), dq.as<int32_t>(),
@@ -436,10 +436,10 @@ QLDPC_EXPORT int qldpc_circuit_plan_create(const qldpc_circuit_desc *D, const ql
         (rc = P->d_iter_x.ensure(Bz * 4)) || (rc = P->d_list_z.ensure(Bz * 4)) || (rc = P->d_list_x.ensure(Bz * 4)) || (rc = P->d_count.ensure(64)) ||
         (rc = P->d_tally.ensure(QLDPC_TALLY_SLOTS * 8)) || (rc = P->d_clk.ensure(2 * kClkSlots * 16)))
         return fail(rc);
-    if (hipMemset(P->d_clk.p, 0, 2 * kClkSlots * 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
+    if (zero_now(P->d_clk.p, 2 * kClkSlots * 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
     // (round 2 ran sector X on a second stream beside sector Z: two persistent kernels that each own every CU do not overlap -- 177.9 vs 178.7 ms
     // per step -- and the small launches queued behind them polluted the profile; everything runs on the caller's stream now)
-    if (hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
+    if (zero_now(P->d_tally.p, QLDPC_TALLY_SLOTS * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
     *out = P;
     return QLDPC_OK;
 }
@@ -552,7 +552,7 @@ QLDPC_EXPORT int qldpc_circuit_plan_read(qldpc_circuit_plan *P, void *stream, in
     if (P->side) QLDPC_HIP_TRY(hipStreamSynchronize(P->side));
     drain_phases(P, true);                                           // everything enqueued has finished: fold the brackets, recycle their events
     QLDPC_HIP_TRY(hipMemcpy(tally, P->d_tally.p, QLDPC_TALLY_SLOTS * 8, hipMemcpyDeviceToHost));
-    if (clear) QLDPC_HIP_TRY(hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8));
+    if (clear) QLDPC_HIP_TRY(zero_now(P->d_tally.p, QLDPC_TALLY_SLOTS * 8));
     return QLDPC_OK;
 }
 

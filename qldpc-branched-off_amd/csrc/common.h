@@ -34,6 +34,15 @@ void set_error(const char *fmt, ...);
         }                                         \
     } while (0)
 
+// Zeroes device memory and WAITS for it.  hipMemset returns once the fill is queued on the null stream, and the null stream is not ordered against
+// hipStreamNonBlocking streams: a kernel enqueued on such a stream right after a bare hipMemset can start before the fill has run.  Round 4 found
+// a lane's OSD-0 ticket counter zeroed in the middle of the lane's first launch that way (profiles/r04_experiments.txt, item 5; the hand-out in
+// isolation: tools/microbench/ticket_race.hip).  Every "zero this before anyone uses it" in the library goes through here.
+inline hipError_t zero_now(void *p, size_t bytes) {
+    const hipError_t e = hipMemsetAsync(p, 0, bytes, nullptr);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 // Checks that a gfx9 device is present and selects it. Returns QLDPC_OK or QLDPC_ERR_NO_DEVICE.
 int use_device(int device);
 

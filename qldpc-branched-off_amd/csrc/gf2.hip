@@ -469,8 +469,8 @@ QLDPC_EXPORT int qldpc_gf2_eliminate_packed(int64_t B, int m, int n, int nwords,
         return rc;
     QLDPC_HIP_TRY(hipMemcpy(dA.p, A, (size_t)B * m * nwords * 8, hipMemcpyHostToDevice));
     QLDPC_HIP_TRY(hipMemcpy(db.p, b, (size_t)B * m, hipMemcpyHostToDevice));
-    QLDPC_HIP_TRY(hipMemset(dpr.p, 0, (size_t)B * maxp * 8));
-    QLDPC_HIP_TRY(hipMemset(dpc.p, 0, (size_t)B * maxp * 8));
+    QLDPC_HIP_TRY(zero_now(dpr.p, (size_t)B * maxp * 8));
+    QLDPC_HIP_TRY(zero_now(dpc.p, (size_t)B * maxp * 8));
     hipLaunchKernelGGL(gf2_eliminate_packed_kernel, dim3((unsigned)B), dim3(m >= 512 ? 1024 : 256), lds, nullptr, m, n, nwords,
                        dA.as<uint64_t>(), db.as<uint8_t>(), dpr.as<int64_t>(), dpc.as<int64_t>(), dn.as<int32_t>());
     QLDPC_HIP_TRY(hipGetLastError());
@@ -504,8 +504,8 @@ QLDPC_EXPORT int qldpc_gf2_eliminate(int64_t B, int m, int n, uint8_t *A, uint8_
         return rc;
     QLDPC_HIP_TRY(hipMemcpy(dA8.p, A, (size_t)rows * n, hipMemcpyHostToDevice));
     QLDPC_HIP_TRY(hipMemcpy(db.p, b, (size_t)rows, hipMemcpyHostToDevice));
-    QLDPC_HIP_TRY(hipMemset(dpr.p, 0, (size_t)B * maxp * 8));
-    QLDPC_HIP_TRY(hipMemset(dpc.p, 0, (size_t)B * maxp * 8));
+    QLDPC_HIP_TRY(zero_now(dpr.p, (size_t)B * maxp * 8));
+    QLDPC_HIP_TRY(zero_now(dpc.p, (size_t)B * maxp * 8));
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((rows * nwords + 255) / 256)), dim3(256), 0, nullptr, rows, n, nwords,
                        dA8.as<uint8_t>(), dA.as<uint64_t>());
     hipLaunchKernelGGL(gf2_eliminate_packed_kernel, dim3((unsigned)B), dim3(m >= 512 ? 1024 : 256), lds, nullptr, m, n, nwords,
@@ -1224,7 +1224,7 @@ unsigned long long *osd_timer_buffer() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!d_buf[dev]) {
         if (hipMalloc(reinterpret_cast<void **>(&d_buf[dev]), 32 * 8) != hipSuccess) { d_buf[dev] = nullptr; return nullptr; }
-        (void)hipMemset(d_buf[dev], 0, 32 * 8);
+        (void)zero_now(d_buf[dev], 32 * 8);
     }
     return d_buf[dev];
 #else
@@ -1242,6 +1242,6 @@ QLDPC_EXPORT int qldpc_osd_timers_read(uint64_t *out, int reset) {
     if (!d) { qldpc::set_error("OSD phase timers are compiled out of this build (make -C csrc timers)"); return QLDPC_ERR_UNSUPPORTED; }
     QLDPC_HIP_TRY(hipDeviceSynchronize());
     QLDPC_HIP_TRY(hipMemcpy(out, d, 32 * 8, hipMemcpyDeviceToHost));
-    if (reset) QLDPC_HIP_TRY(hipMemset(d, 0, 32 * 8));
+    if (reset) QLDPC_HIP_TRY(zero_now(d, 32 * 8));
     return QLDPC_OK;
 }

@@ -209,11 +209,11 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
         (rc = P->d_iter.ensure(batch * 4)) || (rc = P->d_tally.ensure(QLDPC_TALLY_SLOTS * 8)) ||
         (rc = P->d_list.ensure(batch * 4)) || (rc = P->d_count.ensure(16)))
         return fail(rc);
-    if (hipMemset(P->d_count.p, 0, 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
+    if (zero_now(P->d_count.p, 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
     if (hipMemcpy(P->d_alpha.p, P->alpha.data(), P->alpha.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(P->d_prior.p, prior.data(), prior.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(P->d_Lmask.p, Lmask.data(), Lmask.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8) != hipSuccess) {
+        zero_now(P->d_tally.p, QLDPC_TALLY_SLOTS * 8) != hipSuccess) {
         set_error("plan upload failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(QLDPC_ERR_HIP);
     }
@@ -239,7 +239,7 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
         if (flags & QLDPC_FLAG_CLOCK_PROBE) {
             // two probe buffers: [0] the full decoder's workgroups, [1] the first-iteration kernel's
             if ((rc = P->d_clk.ensure(4 * kClkSlots * 8)) != QLDPC_OK) return fail(rc);
-            if (hipMemset(P->d_clk.p, 0, 4 * kClkSlots * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
+            if (zero_now(P->d_clk.p, 4 * kClkSlots * 8) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
         }
         if ((rc = mc_regular_fill_cold(P->d_cold.p, P->d_tally.as<unsigned long long>(), P->d_count.as<int32_t>(), P->d_list.as<int32_t>(),
                                        P->d_synd.as<int8_t>(), P->d_err.as<int8_t>(), P->d_dec.as<int8_t>(), P->d_llr.as<double>(),
@@ -263,7 +263,7 @@ QLDPC_EXPORT int qldpc_cc_plan_create(const qldpc_graph *g, int k, const uint8_t
                     (rc = Ln.list.ensure(batch * 4)) || (rc = Ln.count.ensure(16)) || (rc = Ln.cold.ensure(mc_regular_cold_bytes())) ||
                     (P->first_ok && (rc = Ln.cont.ensure(batch * 4))))
                     return fail(rc);
-                if (hipMemset(Ln.count.p, 0, 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
+                if (zero_now(Ln.count.p, 16) != hipSuccess) { set_error("memset failed"); return fail(QLDPC_ERR_HIP); }
                 if ((rc = mc_regular_fill_cold(Ln.cold.p, P->d_tally.as<unsigned long long>(), Ln.count.as<int32_t>(), Ln.list.as<int32_t>(), Ln.synd.as<int8_t>(),
                                                Ln.err.as<int8_t>(), Ln.dec.as<int8_t>(), Ln.llr.as<double>(),
                                                (flags & QLDPC_FLAG_CLOCK_PROBE) ? P->d_clk.as<unsigned long long>() : nullptr)) != QLDPC_OK)
@@ -443,7 +443,7 @@ QLDPC_EXPORT int qldpc_cc_plan_read(qldpc_cc_plan *P, void *stream, int clear, i
     if (P->side) QLDPC_HIP_TRY(hipStreamSynchronize(P->side));
     for (auto &Ln : P->lanes) { if (Ln.st) QLDPC_HIP_TRY(hipStreamSynchronize(Ln.st)); Ln.tail_pending = false; }
     QLDPC_HIP_TRY(hipMemcpy(tally, P->d_tally.p, QLDPC_TALLY_SLOTS * 8, hipMemcpyDeviceToHost));
-    if (clear) QLDPC_HIP_TRY(hipMemset(P->d_tally.p, 0, QLDPC_TALLY_SLOTS * 8));
+    if (clear) QLDPC_HIP_TRY(zero_now(P->d_tally.p, QLDPC_TALLY_SLOTS * 8));
     return QLDPC_OK;
 }
 

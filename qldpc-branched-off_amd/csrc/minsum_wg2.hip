@@ -73,6 +73,20 @@ __device__ __forceinline__ double signed_mag(double mag, uint32_t t) {
 
 struct Wg2Row { bool par; uint32_t pxw; double min1, min2; int arg; uint32_t nA, nB; };
 
+// An LDS read at an ABSOLUTE LDS byte address.  The kernel has no static LDS, so its dynamic LDS starts at address 0 (checked once per launch, below); reading
+// through the `lds` symbol instead makes the compiler add the symbol's (zero, but relocatable) address to every hoisted per-edge offset again: one v_add per edge.
+typedef __attribute__((address_space(3))) const double wg2_lds_f64;
+__device__ __forceinline__ double wg2_lds_read_f64(uint32_t addr) { return *reinterpret_cast<wg2_lds_f64 *>(static_cast<uintptr_t>(addr)); }
+typedef double wg2_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const wg2_d2 wg2_lds_f64x2;
+typedef __attribute__((address_space(3))) const unsigned long long wg2_lds_u64;
+typedef __attribute__((address_space(3))) const uint16_t wg2_lds_u16;
+typedef __attribute__((address_space(3))) double wg2_lds_f64w;
+__device__ __forceinline__ double2 wg2_lds_read_f64x2(uint32_t addr) { const wg2_d2 t = *reinterpret_cast<wg2_lds_f64x2 *>(static_cast<uintptr_t>(addr)); return make_double2(t.x, t.y); }
+__device__ __forceinline__ unsigned long long wg2_lds_read_u64(uint32_t addr) { return *reinterpret_cast<wg2_lds_u64 *>(static_cast<uintptr_t>(addr)); }
+__device__ __forceinline__ uint32_t wg2_lds_read_u16(uint32_t addr) { return *reinterpret_cast<wg2_lds_u16 *>(static_cast<uintptr_t>(addr)); }
+__device__ __forceinline__ void wg2_lds_write_f64(uint32_t addr, double x) { *reinterpret_cast<wg2_lds_f64w *>(static_cast<uintptr_t>(addr)) = x; }
+
 // Eight edge slots K0 .. K0 + 7 of the thread's row.  CNT = 8: every lane of the wave has all eight; 1 .. 7: every lane has exactly CNT of them
 // (rows are handed out in degree order, a wave's rows share a degree but for three waves); 0: per-lane degree, predicated.
 template <bool NANSEL, bool FIRST, int K0, int CNT>
@@ -84,7 +98,7 @@ __device__ __forceinline__ void wg2_chunk(const uint32_t (&idx)[4 * kWg2Chunks],
     for (int u = 0; u < NE; u++) {
         const uint32_t w = idx[(K0 + u) >> 1];
         const uint32_t off = ((K0 + u) & 1) ? ((w >> 13) & 0x7FFF8u) : ((w << 3) & 0x7FFF8u);          // column slot * 8
-        v[u] = *reinterpret_cast<const double *>(Vb + off);
+        v[u] = wg2_lds_read_f64(kWg2OffV + off);
     }
 #pragma unroll
     for (int u = 0; u < NE; u++) {
@@ -150,17 +164,17 @@ __device__ __forceinline__ void wg2_row(const uint32_t (&idx)[4 * kWg2Chunks], c
 // the D edges of one column, every lane of the wave has exactly D: entries, then the three words of each check state, then the sum in
 // ascending check order (kernels.py:316).  ST64: the check states as 64-bit words, three per row slot (P1, P2, sign word).
 template <int D>
-__device__ __forceinline__ double wg2_col(const uint16_t *__restrict__ EL, const int (&eoff)[8], int c, const unsigned char *__restrict__ lds0) {
+__device__ __forceinline__ double wg2_col(uint32_t el_addr, const int (&eoff)[8], int c) {       // el_addr: LDS byte address of the edge list
     uint32_t e[D];
     double2 pp[D];
     unsigned long long si[D];
 #pragma unroll
-    for (int u = 0; u < D; u++) e[u] = EL[eoff[u] + c];
+    for (int u = 0; u < D; u++) e[u] = wg2_lds_read_u16(el_addr + 2u * (uint32_t)(eoff[u] + c));
 #pragma unroll
     for (int u = 0; u < D; u++) {                                                            // row slot = e >> 6: byte offsets 16 * slot and 8 * slot
         const uint32_t a = (e[u] >> 2) & 0x3FF0u;
-        pp[u] = *reinterpret_cast<const double2 *>(lds0 + a);
-        si[u] = *reinterpret_cast<const unsigned long long *>(lds0 + kWg2OffSI + (a >> 1));
+        pp[u] = wg2_lds_read_f64x2(a);
+        si[u] = wg2_lds_read_u64(kWg2OffSI + (a >> 1));
     }
     double s = 0.0;                                                                          // kernels.py:279
 #pragma unroll
@@ -172,10 +186,10 @@ __device__ __forceinline__ double wg2_col(const uint16_t *__restrict__ EL, const
     return s;
 }
 
-__device__ __forceinline__ double wg2_edge(uint32_t e, const unsigned char *__restrict__ lds0) {
+__device__ __forceinline__ double wg2_edge(uint32_t e) {
     const uint32_t a = (e >> 2) & 0x3FF0u;
-    const double2 pp = *reinterpret_cast<const double2 *>(lds0 + a);
-    const unsigned long long w = *reinterpret_cast<const unsigned long long *>(lds0 + kWg2OffSI + (a >> 1));
+    const double2 pp = wg2_lds_read_f64x2(a);
+    const unsigned long long w = wg2_lds_read_u64(kWg2OffSI + (a >> 1));
     const uint32_t k = e & 63u;
     return signed_mag((k == ((uint32_t)w & 255u)) ? pp.y : pp.x, (uint32_t)((w << k) >> 32));
 }
@@ -192,6 +206,7 @@ __global__ __launch_bounds__(1024) void minsum_wg2_kernel(Wg2Args A) {
     const int m = A.m, n = A.n, max_iter = A.max_iter, tid = threadIdx.x, T = blockDim.x;
     const double clip = A.clip, nclip = -A.clip;
     const ClkStamp clk0 = clk_begin(A.clk);
+    if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char *)lds) != 0) __builtin_trap();      // (see wg2_lds_read_f64)
     const int deg = (tid < m) ? (int)A.degr[tid] : 0;                                        // the thread's row slot, constant over shots
     const int row_own = (tid < m) ? A.row_of_slot[tid] : 0;
     uint32_t idx[4 * kWg2Chunks];                                                            // the row's column slots, two per register (unused: slot 0)
@@ -289,21 +304,21 @@ __global__ __launch_bounds__(1024) void minsum_wg2_kernel(Wg2Args A) {
                     const int dgu = __builtin_amdgcn_readfirstlane(ci.deg);
                     switch (dgu) {
                         case 0: s = 0.0; break;
-                        case 2: s = wg2_col<2>(EL, eoff, c, lds); break;
-                        case 3: s = wg2_col<3>(EL, eoff, c, lds); break;
-                        case 4: s = wg2_col<4>(EL, eoff, c, lds); break;
-                        case 5: s = wg2_col<5>(EL, eoff, c, lds); break;
-                        case 6: s = wg2_col<6>(EL, eoff, c, lds); break;
+                        case 2: s = wg2_col<2>((uint32_t)A.offEL, eoff, c); break;
+                        case 3: s = wg2_col<3>((uint32_t)A.offEL, eoff, c); break;
+                        case 4: s = wg2_col<4>((uint32_t)A.offEL, eoff, c); break;
+                        case 5: s = wg2_col<5>((uint32_t)A.offEL, eoff, c); break;
+                        case 6: s = wg2_col<6>((uint32_t)A.offEL, eoff, c); break;
                         default: {                                                           // degree 1, 7, 8
                             s = 0.0;
-                            for (int d = 0; d < dgu; d++) s += wg2_edge(EL[eoff[d] + c], lds);
+                            for (int d = 0; d < dgu; d++) s += wg2_edge(EL[eoff[d] + c]);
                         }
                     }
-                    V[c] = s + ci.prior;                                                     // kernels.py:320
+                    wg2_lds_write_f64(kWg2OffV + 8u * (uint32_t)c, s + ci.prior);            // kernels.py:320
                 } else if (c < n) {                                                          // a chunk that mixes classes (or the ragged last one): per-lane degree and prior
                     const int dj = A.degc[c];
                     double s = 0.0;
-                    for (int d = 0; d < dj; d++) s += wg2_edge(EL[eoff[d] + c], lds);
+                    for (int d = 0; d < dj; d++) s += wg2_edge(EL[eoff[d] + c]);
                     V[c] = s + A.prior_s[c];
                 }
             }

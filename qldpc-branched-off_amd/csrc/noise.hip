@@ -131,7 +131,7 @@ QLDPC_EXPORT int qldpc_noisy_circuit_batch(int64_t B, int64_t len, const int32_t
         QLDPC_HIP_TRY(hipMemcpy(drt.p, rt, B * n_locs * 4, hipMemcpyHostToDevice));
     }
     if (cap) {
-        QLDPC_HIP_TRY(hipMemset(doo.p, 0, B * cap * 4)); QLDPC_HIP_TRY(hipMemset(do1.p, 0, B * cap * 4)); QLDPC_HIP_TRY(hipMemset(do2.p, 0, B * cap * 4));
+        QLDPC_HIP_TRY(zero_now(doo.p, B * cap * 4)); QLDPC_HIP_TRY(zero_now(do1.p, B * cap * 4)); QLDPC_HIP_TRY(zero_now(do2.p, B * cap * 4));
     }
     hipLaunchKernelGGL(noisy_circuit_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, nullptr, B, len, dops.as<int32_t>(), dq1.as<int32_t>(),
                        dq2.as<int32_t>(), p, n_locs, drv.as<double>(), drp.as<int32_t>(), drt.as<int32_t>(), cap, doo.as<int32_t>(),

@@ -271,7 +271,7 @@ int osd_small_queue(const qldpc_graph *g, int **queue) {
     const bool fresh = g->ws_squeue.p == nullptr;
     int rc = g->ws_squeue.ensure(16);
     if (rc != QLDPC_OK) return rc;
-    if (fresh) QLDPC_HIP_TRY(hipMemset(g->ws_squeue.p, 0, 16));
+    if (fresh) QLDPC_HIP_TRY(zero_now(g->ws_squeue.p, 16));
     *queue = g->ws_squeue.as<int>();
     return QLDPC_OK;
 }

@@ -137,7 +137,7 @@ static int check_pass_host(const qldpc_graph *g, int64_t B, const double *Q, con
     if ((rc = dQ.alloc(B * nnz * 8)) || (rc = dS.alloc(B * m * 8)) || (rc = dR.alloc(B * nnz * 8)) || (rc = dRs.alloc(B * n * 8))) return rc;
     if (nnz) QLDPC_HIP_TRY(hipMemcpy(dQ.p, Q, B * nnz * 8, hipMemcpyHostToDevice));
     if (m) QLDPC_HIP_TRY(hipMemcpy(dS.p, ssign, B * m * 8, hipMemcpyHostToDevice));
-    QLDPC_HIP_TRY(hipMemset(dR.p, 0, B * nnz * 8 + (nnz ? 0 : 16)));
+    QLDPC_HIP_TRY(zero_now(dR.p, B * nnz * 8 + (nnz ? 0 : 16)));
     if (B * m > 0) {
         if (bp) hipLaunchKernelGGL(check_pass_kernel<true>, dim3(blocks(B * m)), dim3(256), 0, nullptr, B, (int)m, (int)nnz, g->d_indptr,
                                    dQ.as<double>(), dS.as<double>(), (const uint8_t *)nullptr, param, dR.as<double>());
@@ -183,7 +183,7 @@ QLDPC_EXPORT int qldpc_bp_decode_batch(const qldpc_graph *g, int64_t B, const in
     size_t tot = B * nnz; if (B * m > tot) tot = B * m; if ((size_t)B > tot) tot = B;
     hipLaunchKernelGGL(bp_init_kernel, dim3(blocks(tot)), dim3(256), 0, nullptr, B, (int)m, (int)n, (int)nnz, g->d_indices, dpr.as<double>(),
                        dsy.as<int8_t>(), dQ.as<double>(), dS.as<double>(), ddone.as<uint8_t>(), dunsat.as<uint8_t>());
-    QLDPC_HIP_TRY(hipMemset(dR.p, 0, B * nnz * 8 + (nnz ? 0 : 16)));
+    QLDPC_HIP_TRY(zero_now(dR.p, B * nnz * 8 + (nnz ? 0 : 16)));
     for (int it = 0; it < max_iter; it++) {
         if (B * m > 0)
             hipLaunchKernelGGL(check_pass_kernel<true>, dim3(blocks(B * m)), dim3(256), 0, nullptr, B, (int)m, (int)nnz, g->d_indptr,
@@ -440,7 +440,7 @@ QLDPC_EXPORT int qldpc_msgstats_histogram(qldpc_msgstats *S, const double *edges
     DevTmp d_edges, d_hist;
     if ((rc = d_edges.alloc((bins + 1) * 8)) || (rc = d_hist.alloc(2 * bins * 8))) return rc;
     QLDPC_HIP_TRY(hipMemcpy(d_edges.p, edges, (bins + 1) * 8, hipMemcpyHostToDevice));
-    QLDPC_HIP_TRY(hipMemset(d_hist.p, 0, 2 * bins * 8));
+    QLDPC_HIP_TRY(zero_now(d_hist.p, 2 * bins * 8));
     const int64_t total = S->B * (int64_t)S->L;
     if (total > 0) {
         // each block counts into 32-bit LDS bins: keep its share of the samples below 2^31

@@ -403,6 +403,29 @@ def test_code_capacity_tally_matches_oracle(L, oracle):
     assert ref[0] == 1000
 
 
+def test_code_capacity_small_pieces_many_failures_per_piece(L, oracle):
+    """Fresh plans whose every piece lists thousands of BP failures (p = 0.08, three iterations): the one-wave OSD-0 kernels then hand most records out
+    through their ticket counter, from the FIRST launch of every lane on.  Round 4's soak found that counter zeroed in the middle of such a first launch
+    (a bare hipMemset is queued on the null stream, which the lanes' non-blocking streams do not wait for): records solved and judged twice, a
+    logical-error count a few hundred too high, only with the lanes on hardware queues of their own.  Several fresh plans, shots split over calls."""
+    from qldpc_amd.data import load_code
+    c = load_code("bb72")
+    ip, ix, n = c["Hx_indptr"], c["Hx_indices"], int(c["n"])
+    graph = L.Graph(ip, ix, n)
+    seed = 2982864118342514790
+    for flags in (L.FLAG_KERNEL_GENERIC, L.FLAG_FIXED_ITERS, 0):
+        for batch, runs in ((4096, (81959,)), (4096, (100, 39900, 42000)), (40000, (120000,))):
+            plan = L.CodeCapacityPlan(graph, c["Lx"], 0.08, max_iter=3, use_osd=True, flags=flags, batch=batch)
+            want, begin = np.zeros(16, np.int64), 1000
+            for count in runs:
+                plan.run(seed, begin, count)
+                want += oracle.cc_sample_decode_tally(ip, ix, n, c["Lx"], 0.08, seed, begin, count, max_iter=3, use_osd=True, threads=0)
+                begin += count
+            got = plan.read()
+            plan.close()
+            assert np.array_equal(got, want), (flags, batch, runs, got.tolist(), want.tolist())
+
+
 @pytest.fixture
 def options(L):
     """qldpc_set_option switches are process-wide: put the defaults back after a test that turns them"""

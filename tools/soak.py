@@ -142,7 +142,9 @@ while time.time() < t_end:
         p = float(rng.choice([0.002, 0.01, 0.04, 0.09]))
         E = (rng.random((B, n)) < p).astype(np.int8)
         synd = np.stack([oracle.syndrome_check(ip, ix, e) for e in E])
-        prior = np.full(n, np.log((1 - p) / p)) + (rng.normal(0, 0.5, n) if rng.random() < 0.5 else 0.0)
+        # uniform / three-valued priors take the LDS-resident workgroup decoder on the circuit-level matrices (classes by (degree, prior)), noisy ones its fall-back
+        shape = rng.random()
+        prior = np.full(n, np.log((1 - p) / p)) + (rng.normal(0, 0.5, n) if shape < 0.35 else (rng.choice([0.0, 1.25, -0.75], n) if shape < 0.7 else 0.0))
         if rng.random() < 0.15:
             prior[rng.integers(0, n)] = rng.choice([0.0, -0.0, np.inf, -np.inf, np.nan])
         mode, alpha = [("dynamical", 1.0), ("alvarado", float(rng.uniform(0.3, 1.1))), ("alvarado-autoregressive", rng.uniform(0.3, 1.0, int(rng.integers(1, 6))))][int(rng.integers(0, 3))]
@@ -154,7 +156,7 @@ while time.time() < t_end:
         if env:
             flags |= L.FLAG_WG_VGLOBAL
         if n > 1000 and rng.random() < 0.3:
-            flags |= int(rng.choice([L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC]))
+            flags |= int(rng.choice([L.FLAG_WG_ROWMAJOR, L.FLAG_WG_GENERIC, L.FLAG_WG_TABLES]))
         try:
             out = L.minsum_decode_batch(g, synd, prior, iters, mode, alpha, damping=damping, clip_llr=clip, flags=flags)
         except L.QldpcError as e:
