@@ -54,6 +54,12 @@ __device__ __forceinline__ void gjg_pivot_step(GjgBlock &S, int lane) {
     S.nops++;
 }
 
+// b (row `brow` of the word-major U, in global memory) has no one in a row outside `used` (LDS): every wave evaluates it for itself, lane = word
+__device__ __forceinline__ bool gjg_residual_gone(const unsigned long long *U, const unsigned long long *used, int brow, int ms, int mw, int lane) {
+    const unsigned long long z = (lane < mw) ? (U[(size_t)lane * ms + brow] & ~used[lane]) : 0ull;
+    return __ballot(z != 0ull) == 0ull;
+}
+
 __global__ __launch_bounds__(1024) void osd0_gjg_kernel(OsdGjgArgs PP) {
     extern __shared__ unsigned char lds[];
     const OsdGjArgs &P = PP.A;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(1024) void osd0_gjg_kernel(OsdGjgArgs PP) {
         int row = 0, par = 0;                                                // pivots so far; parity of the block count (usedw buffer in force)
         unsigned long long d_cols = 0, d_chunks = 0, d_kills = 0, d_blocks = 0, c_p1 = 0, c_p2 = 0, c_p3 = 0, c_kill = 0;
         const long long t_sorted = OSD_CLOCK();
-        bool finished = (P.rankH == 0);
+        bool finished = (P.rankH == 0) || gjg_residual_gone(U, usedw + 64 * par, brow, ms, mw, lane);
         for (int base = 0; base < n && !finished; base += K) {
             const int L = min(K, n - base);
             d_chunks++;
@@ -287,6 +293,8 @@ __global__ __launch_bounds__(1024) void osd0_gjg_kernel(OsdGjgArgs PP) {
                 __syncthreads();
                 c_p3 += OSD_CLOCK() - tp; tp = OSD_CLOCK();
                 if (row >= P.rankH || row >= m) { finished = true; break; }
+                // the residual syndrome is gone (osd_gj.hip: b has no one left in an unused row, so no later pivot changes b and every later column gets e = 0)
+                if (gjg_residual_gone(U, usedw + 64 * par, brow, ms, mw, lane)) { finished = true; break; }
                 if (anydep && (d_blocks % kGjKillEvery) == 0) kill_due = true;       // done by the idle waves beside the next block's pivot chain
             }
             __syncthreads();      // nobody may refill alive[]/sidx[] while others still use them
