@@ -30,34 +30,22 @@ __device__ __forceinline__ unsigned long long osd_key(double x) {
 // from (a) every wave owning a contiguous range of positions and walking it in order, (b) a lane's rank among the lanes of its step
 // with the same digit (8 ballots), (c) an exclusive scan of the [digit][wave] counters in digit-major order.
 // keys [n], pa / pb [n] each, cnt [256][waves] + [waves] are scratch (LDS or global); the order is left in ordw [n].  Whole workgroup.
-__device__ __forceinline__ void osd_radix_sort(const double *__restrict__ llr, int n, unsigned long long *keys, uint16_t *pa, uint16_t *pb,
-                                               unsigned *cnt, uint16_t *ordw) {
+// The passes: orders the index list pa [0 .. len) (initially in the order ties are to come out in) by keys [pa [i]] and leaves it in out [0 .. len).
+// KS = steps of 64 positions a wave keeps in registers per pass (lists of up to 1024 * KS entries; longer ones walk their range in a loop; KS = 0: loop only).
+template <int KS>
+__device__ __forceinline__ void osd_radix_passes(const unsigned long long *keys, int len, uint16_t *pa, uint16_t *pb, unsigned *cnt, uint16_t *out) {
+    const int n = len;
     const int tid = threadIdx.x, T = blockDim.x;
     const int NW = T >> 6, wv = tid >> 6, lane = tid & 63;
     unsigned *wsum = cnt + 256 * NW;
     const int span = (((n + NW - 1) / NW) + 63) & ~63;                                      // positions per wave, a multiple of 64
     const int wbeg = wv * span, wend = min(n, wbeg + span);
-    for (int j = tid; j < n; j += T) { keys[j] = osd_key(llr[j]); pa[j] = (uint16_t)j; }
-    if (n <= 512) {
-        // small matrices (code capacity): one pass -- position of column i = number of columns with a smaller key, or the same key and a
-        // smaller index.  n^2 / T uniform (broadcast) key reads per thread instead of 8 passes x 4 barriers: the OSD kernel's latency on a
-        // handful of shots is what a Monte-Carlo step of the early-exit pipeline waits for.
-        __syncthreads();
-        for (int i = tid; i < n; i += T) {
-            const unsigned long long ki = keys[i];
-            int rank = 0;
-            for (int j = 0; j < n; j++) { const unsigned long long kj = keys[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
-            ordw[rank] = (uint16_t)i;
-        }
-        __syncthreads();
-        return;
-    }
     for (int pass = 0; pass < 8; pass++) {
         const int shift = 8 * pass;
         for (int e = tid; e < 256 * NW; e += T) cnt[e] = 0u;
         __syncthreads();
-        constexpr int kSteps = 10;                                                          // steps of 64 positions kept in registers
-        const bool cached = (span <= 64 * kSteps);
+        constexpr int kSteps = KS > 0 ? KS : 1;                                             // steps of 64 positions kept in registers
+        const bool cached = KS > 0 && (span <= 64 * kSteps);
         int cj[kSteps];
         unsigned cd[kSteps];
         unsigned long long csame[kSteps];
@@ -140,10 +128,139 @@ __device__ __forceinline__ void osd_radix_sort(const double *__restrict__ llr, i
         }
         uint16_t *tsw = pa; pa = pb; pb = tsw;
     }
-    for (int j = tid; j < n; j += T) ordw[j] = pa[j];
+    for (int j = tid; j < n; j += T) out[j] = pa[j];
     __syncthreads();
 }
 
+
+
+__device__ __forceinline__ void osd_radix_sort(const double *__restrict__ llr, int n, unsigned long long *keys, uint16_t *pa, uint16_t *pb,
+                                               unsigned *cnt, uint16_t *ordw) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int j = tid; j < n; j += T) { keys[j] = osd_key(llr[j]); pa[j] = (uint16_t)j; }
+    if (n <= 512) {
+        // small matrices (code capacity): one pass -- position of column i = number of columns with a smaller key, or the same key and a
+        // smaller index.  n^2 / T uniform (broadcast) key reads per thread instead of 8 passes x 4 barriers: the OSD kernel's latency on a
+        // handful of shots is what a Monte-Carlo step of the early-exit pipeline waits for.
+        __syncthreads();
+        for (int i = tid; i < n; i += T) {
+            const unsigned long long ki = keys[i];
+            int rank = 0;
+            for (int j = 0; j < n; j++) { const unsigned long long kj = keys[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+            ordw[rank] = (uint16_t)i;
+        }
+        __syncthreads();
+        return;
+    }
+    osd_radix_passes<10>(keys, n, pa, pb, cnt, ordw);
+}
+
+// The first columns of that order only.  The free-pivot kernels stop their sweep when the residual syndrome is gone (osd_gj.hip) -- on the circuit-level
+// matrices after ~170 of 8 800 columns -- so a full sort is mostly wasted: this one finds a key bound tau with `want` <= #{key <= tau} (a radix select:
+// 8-bit histograms from the top byte down, until the bin that holds the want-th key is small), splits the columns into S = {key <= tau} and the rest, both
+// in index order, and sorts S alone.  Returns Kt = |S|: ordw [0 .. Kt) is the head of the full order, ordw [Kt .. n) the other columns in INDEX order --
+// a caller that gets that far sorts them then (osd_sort_rest).  Scratch as for osd_radix_sort; cnt needs 256 * waves + waves + 8 words.
+__device__ __forceinline__ int osd_radix_sort_head(const double *__restrict__ llr, int n, int want, unsigned long long *keys, uint16_t *pa, uint16_t *pb,
+                                                   unsigned *cnt, uint16_t *ordw) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int NW = T >> 6, wv = tid >> 6, lane = tid & 63;
+    if (want <= 0 || n <= 512 || n < 2 * want) { osd_radix_sort(llr, n, keys, pa, pb, cnt, ordw); return n; }
+    for (int j = tid; j < n; j += T) keys[j] = osd_key(llr[j]);
+    unsigned *hist = cnt;                                                                   // [256]
+    unsigned *sel = cnt + 256;                                                              // [0] bin, [1] keys below the bin, [2] keys in it
+    unsigned long long prefix = 0ull;
+    int shift = 56, below = 0, Kt = n;
+    for (;; shift -= 8) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        for (int j0 = 0; j0 < n; j0 += T) {
+            // keys crowd into a few bins at the top levels (the exponent bytes): the lanes of a wave that share a digit add their count with ONE atomic
+            // (64 atomics on one LDS address take 64 passes of the pipe); what is left after four such groups goes lane by lane
+            const int j = j0 + tid;
+            const unsigned long long k = (j < n) ? keys[j] : 0ull;
+            const unsigned d = (unsigned)(k >> shift) & 255u;
+            bool take = (j < n) && (shift == 56 || (k >> (shift + 8)) == prefix);
+            unsigned long long active = __ballot(take);
+            for (int grp = 0; grp < 4 && active != 0ull; grp++) {
+                const int leader = __builtin_ctzll(active);
+                const unsigned dl = (unsigned)__builtin_amdgcn_readlane((int)d, leader);
+                const unsigned long long same = __ballot(take && d == dl);
+                if (lane == leader) atomicAdd(&hist[dl], (unsigned)__builtin_popcountll(same));
+                if (d == dl) take = false;
+                active &= ~same;
+            }
+            if (take) atomicAdd(&hist[d], 1u);
+        }
+        __syncthreads();
+        if (wv == 0) {                                                                      // lane: bins 4 lane .. 4 lane + 3
+            unsigned v[4], sum = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] = hist[4 * lane + e]; sum += v[e]; }
+            unsigned inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+            unsigned run = (unsigned)below + inc - sum;
+            int found = -1;
+            unsigned fbelow = 0u, fin = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (found < 0 && run + v[e] >= (unsigned)want) { found = 4 * lane + e; fbelow = run; fin = v[e]; }
+                run += v[e];
+            }
+            const unsigned long long bal = __ballot(found >= 0);                            // (n >= want: some bin reaches it)
+            if (bal != 0ull && lane == __builtin_ctzll(bal)) { sel[0] = (unsigned)found; sel[1] = fbelow; sel[2] = fin; }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (unsigned long long)sel[0];
+        below = (int)sel[1];
+        Kt = below + (int)sel[2];
+        __syncthreads();                                                                    // (hist / sel are rewritten by the next level)
+        if (Kt <= want + want / 2 || shift == 0) break;
+    }
+    // stable split: every wave owns a contiguous range of column indices
+    unsigned *wsum = cnt + 264;
+    const int span = (((n + NW - 1) / NW) + 63) & ~63;
+    const int wbeg = min(n, wv * span), wend = min(n, wbeg + span);
+    int mine = 0;
+    for (int p0 = wbeg; p0 < wend; p0 += 64) {
+        const int j = p0 + lane;
+        const bool in = (j < wend) && (keys[j] >> shift) <= prefix;
+        mine += __builtin_popcountll(__ballot(in));
+    }
+    if (lane == 0) wsum[wv] = (unsigned)mine;
+    __syncthreads();
+    int baseS = 0;
+    for (int w2 = 0; w2 < wv; w2++) baseS += (int)wsum[w2];
+    int baseR = wbeg - baseS;
+    for (int p0 = wbeg; p0 < wend; p0 += 64) {
+        const int j = p0 + lane;
+        const bool valid = j < wend;
+        const bool in = valid && (keys[j] >> shift) <= prefix;
+        const unsigned long long bal = __ballot(in), rest = __ballot(valid) & ~bal, lt = (1ull << lane) - 1ull;
+        if (in) pa[baseS + __builtin_popcountll(bal & lt)] = (uint16_t)j;
+        else if (valid) ordw[Kt + baseR + __builtin_popcountll(rest & lt)] = (uint16_t)j;
+        baseS += __builtin_popcountll(bal);
+        baseR += __builtin_popcountll(rest);
+    }
+    __syncthreads();
+    if (Kt <= 2048) osd_radix_passes<2>(keys, Kt, pa, pb, cnt, ordw);
+    else osd_radix_passes<10>(keys, Kt, pa, pb, cnt, ordw);
+    return Kt;
+}
+
+// ... and the other columns, when a sweep does get past the head: ordw [from .. n) holds them in index order; scratch in GLOBAL memory (the caller's LDS is
+// in use by then): keys [n], pa / pb [n - from] each, cnt as above.
+__device__ __forceinline__ void osd_sort_rest(const double *__restrict__ llr, int n, int from, unsigned long long *keys, uint16_t *pa, uint16_t *pb,
+                                              unsigned *cnt, uint16_t *ordw) {
+    const int tid = threadIdx.x, T = blockDim.x, rest = n - from;
+    for (int j = tid; j < n; j += T) keys[j] = osd_key(llr[j]);
+    for (int i = tid; i < rest; i += T) pa[i] = ordw[from + i];
+    __threadfence_block();
+    __syncthreads();
+    osd_radix_passes<0>(keys, rest, pa, pb, cnt, ordw + from);
+    __threadfence_block();
+    __syncthreads();
+}
 
 // U is stored row-major with an XOR swizzle of the word index when rows are 16 words (128 B): conflict-free row-parallel updates
 // (rows of 16 words belong to threads as q = 16 * lane + (wave + lane) % 16, see phase 3: the swizzle follows the lane and moves PAIRS of

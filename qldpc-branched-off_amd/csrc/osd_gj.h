@@ -19,7 +19,12 @@ struct OsdGjArgs {
     int32_t *redo_list, *redo_count;   // shots whose right-hand side is outside the column space (count zeroed before the launch)
     unsigned long long *clk, *dbg;
     int offIdx, offAlive, offRows, offPc, offPr, offR, offBlk, offUsed, offTl;
+    int presort;                   // columns of the sorted head (osd_radix_sort_head; 0 = sort everything up front)
+    unsigned long long *sortws;    // [grid][sortws_words] global scratch for the order of the columns behind the head
+    size_t sortws_words;
 };
+
+int osd_presort_choice();          // option "osd_presort" (options.hip)
 
 int host_gf2_rank(const qldpc_graph *g);
 

@@ -71,12 +71,14 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
         const int8_t *hard = P.hard + shot * n, *synd = P.synd + shot * m;
         int8_t *sol = P.solution + shot * n;
         const long long t_start = OSD_CLOCK();
+        int sorted_upto = n;                                                 // ordw [0 .. sorted_upto) is in order, the rest in index order
         if (!P.ordering) {                                                   // column order: ascending |llr| (osd.py:11-12), ties by index
             unsigned long long *keys = reinterpret_cast<unsigned long long *>(lds);
             uint16_t *pa = reinterpret_cast<uint16_t *>(lds + (size_t)n * 8), *pb = pa + n;
             unsigned *cnt = reinterpret_cast<unsigned *>(lds + (((size_t)n * 12 + 15) & ~(size_t)15));
-            osd_radix_sort(llr, n, keys, pa, pb, cnt, ordw);
+            sorted_upto = osd_radix_sort_head(llr, n, P.presort, keys, pa, pb, cnt, ordw);     // (the head of the order; the sweep rarely gets past it)
         }
+        const long long t_head = OSD_CLOCK();
         // ---- init: T = I, b = s + H hard (osd.py:8-9) ----
         for (int t = tid; t < (m + 2) * mw; t += T) U[t] = 0ull;
         if (tid < 32) {                                                      // rows >= m of the last word never pivot
@@ -115,6 +117,12 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
         for (int base = 0; base < n && !finished; base += K) {
             const int L = min(K, n - base);
             d_chunks++;
+            if (base + L > sorted_upto) {                                    // past the sorted head (rare): the other columns' order, scratch in global memory
+                unsigned long long *gk = P.sortws + (size_t)blockIdx.x * P.sortws_words;
+                uint16_t *gpa = reinterpret_cast<uint16_t *>(gk + n), *gpb = gpa + n;
+                osd_sort_rest(llr, n, sorted_upto, gk, gpa, gpb, reinterpret_cast<unsigned *>(gk + n + (n + 3) / 2), ordw);
+                sorted_upto = n;
+            }
             for (int c = tid; c < L; c += T) {
                 sidx[c] = P.ordering ? (uint16_t)P.ordering[shot * n + base + c] : ordw[base + c];
                 alive[c] = 1;
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
             atomicAdd(&P.dbg[0], 1ull); atomicAdd(&P.dbg[1], d_chunks); atomicAdd(&P.dbg[2], d_cols); atomicAdd(&P.dbg[3], (unsigned long long)row);
             atomicAdd(&P.dbg[4], (unsigned long long)(OSD_CLOCK() - t_start)); atomicAdd(&P.dbg[5], d_kills); atomicAdd(&P.dbg[6], d_blocks);
             atomicAdd(&P.dbg[8], (unsigned long long)(t_sorted - t_start)); atomicAdd(&P.dbg[9], c_p1); atomicAdd(&P.dbg[10], c_p2); atomicAdd(&P.dbg[11], c_p3);
-            atomicAdd(&P.dbg[12], c_kill);
+            atomicAdd(&P.dbg[12], c_kill); atomicAdd(&P.dbg[14], (unsigned long long)(t_head - t_start));          // [14] the sort alone ([8] = sort + initialisation)
         }
 #ifdef QLDPC_OSD_TIMERS
         if (P.dbg && tid == 0) { atomicAdd(&P.dbg[13], c_own); atomicAdd(&P.dbg[7], c_col); }       // [13] wave 0's pivot chains, [7] block collection
@@ -472,8 +480,13 @@ int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d
     if (g->gf2_rank < 0) g->gf2_rank = host_gf2_rank(g);      // callers hold g->mu
     P.rankH = g->gf2_rank;
     const int grid = 512;
-    int rc = g->ws_misc.ensure((size_t)round_up((int64_t)grid * g->n * 2 + 64, 16));
+    // per workgroup: the column order in flight, and global scratch for ordering the columns behind the sorted head (keys, two index arrays, counters)
+    const size_t ord_bytes = (size_t)round_up((int64_t)grid * g->n * 2 + 64, 16);
+    P.sortws_words = (size_t)g->n + (size_t)(g->n + 3) / 2 + (256 * 16 + 64) / 2 + 8;
+    int rc = g->ws_misc.ensure(ord_bytes + (size_t)grid * P.sortws_words * 8);
     if (rc != QLDPC_OK) return rc;
+    P.sortws = reinterpret_cast<unsigned long long *>(g->ws_misc.as<unsigned char>() + ord_bytes);
+    P.presort = osd_presort_choice();
     if ((rc = g->ws_redo.ensure((size_t)(max_listed + 4) * 4)) != QLDPC_OK) return rc;
     if ((rc = g->ws_queue.ensure(16)) != QLDPC_OK) return rc;
     P.ordws = g->ws_misc.as<uint16_t>();

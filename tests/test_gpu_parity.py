@@ -154,6 +154,12 @@ def test_circuit_level_golden(Lb, golden, oracle, tag):
             sol2 = performOSD_enhanced(H, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case], order=0, ordering=stable)
             sol2b = L.osd0_batch(graph, g[f"{s}_syndromes"][case][None], g[f"{s}_llr"][case][None], g[f"{s}_err"][case][None])[0]       # batched entry point, no ordering
             assert np.array_equal(sol2, sol2b)
+            try:        # the device's own sort: a short sorted head + the rest on demand, a head of 2000 columns, the whole order up front (option "osd_presort")
+                for presort in (40, 2000, 0):
+                    L.set_option("osd_presort", presort)
+                    assert np.array_equal(L.osd0_batch(graph, g[f"{s}_syndromes"][case][None], g[f"{s}_llr"][case][None], g[f"{s}_err"][case][None])[0], sol2), (tag, s, t, presort)
+            finally:
+                L.set_option("osd_presort", 1024)
             ref2 = oracle.osd0(ip, ix, n, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case])
             assert np.array_equal(sol2, ref2)
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
@@ -171,6 +177,11 @@ def test_circuit_level_golden(Lb, golden, oracle, tag):
             hd = (rng2.random(n) < 0.05).astype(np.int8)
             assert np.array_equal(performOSD_enhanced(H, sy, ll, hd, order=0, ordering=np.argsort(np.abs(ll), kind="stable")), oracle.osd0(ip, ix, n, sy, ll, hd)), (tag, s, trial)
             assert np.array_equal(L.osd0_batch(graph, sy[None], ll[None], hd[None])[0], oracle.osd0(ip, ix, n, sy, ll, hd)), (tag, s, trial)
+            try:        # (an inconsistent right-hand side: the sweep runs through every chunk, i.e. past any sorted head)
+                L.set_option("osd_presort", 1500)
+                assert np.array_equal(L.osd0_batch(graph, sy[None], ll[None], hd[None])[0], oracle.osd0(ip, ix, n, sy, ll, hd)), (tag, s, trial, "head 1500")
+            finally:
+                L.set_option("osd_presort", 1024)
 
 
 @pytest.mark.parametrize("tag", ["circ72", "circ144"])
@@ -430,7 +441,7 @@ def test_code_capacity_small_pieces_many_failures_per_piece(L, oracle):
 def options(L):
     """qldpc_set_option switches are process-wide: put the defaults back after a test that turns them"""
     yield L.set_option
-    for name, v in (("mc_first_iteration", 1), ("mc_first_bits", 8), ("mc_tail_overlap", 1)):
+    for name, v in (("mc_first_iteration", 1), ("mc_first_bits", 8), ("mc_tail_overlap", 1), ("osd_presort", 1024)):
         L.set_option(name, v)
 
 
@@ -1187,6 +1198,16 @@ def test_random_matrices_osd0_all_kernels(Lb, oracle, monkeypatch):
         for env in for_build(L, (0, L.FLAG_OSD_LDS, L.FLAG_OSD_REFORDER, L.FLAG_OSD_LDS | L.FLAG_OSD_REFORDER, L.FLAG_OSD_UG, L.FLAG_OSD_UG | L.FLAG_OSD_REFORDER, L.FLAG_OSD_GLOBAL)):
             sol = L.osd0_batch(graph, synd, llr, hard, flags=env)
             assert np.array_equal(sol, want), (gi, env, np.flatnonzero((sol != want).any(1)))
+        # the free-pivot kernels sort only a head of the |llr| order up front and the other columns when a sweep gets past it ("osd_presort"): short heads
+        # (the rest path on nearly every shot, the ties above inside and across the head's key bound) and the whole order up front
+        try:
+            for presort in (16, 100, 333, 0):
+                L.set_option("osd_presort", presort)
+                for env in (L.FLAG_OSD_LDS, L.FLAG_OSD_UG):
+                    sol = L.osd0_batch(graph, synd, llr, hard, flags=env)
+                    assert np.array_equal(sol, want), (gi, presort, env, np.flatnonzero((sol != want).any(1)))
+        finally:
+            L.set_option("osd_presort", 1024)
 
 
 def _regular_graph(rng, m, cdeg, vdeg):

@@ -27,11 +27,14 @@ ap.add_argument("--counts-out", default="", help="with --timers: write the OSD-0
 ap.add_argument("--cpu-trials", type=int, default=0, help="also time the CPU checker (C port of the reference loop, all host threads) on this many trials")
 ap.add_argument("--timers", action="store_true", help="load libqldpc_hip_timers.so (make -C csrc timers): in-kernel phase counters")
 ap.add_argument("--build", default="", help="a library file name in csrc/ (A/B builds made by tools/ab_build.sh)")
+ap.add_argument("--opt", default="", help="qldpc_set_option settings, e.g. osd_presort=0")
 a = ap.parse_args()
 if a.build:
     _lib.select_build(a.build)
 elif a.timers:
     _lib.select_build("timers")
+for kv in filter(None, a.opt.split(",")):
+    _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 d = load_circuit_matrices(a.tag)
 c = load_code(str(d["code"]))
 cb = BBCodeCircuit(c["Hx"], c["Hz"], num_cycles=int(d["num_cycles"]), ell=c["ell"], m=c["m_dim"], a_x_powers=c["a_x_powers"],
@@ -80,7 +83,7 @@ for rep in range(a.reps):
                   f"+ variable {h[21] / h[17]:.0f} + barrier {h[22] / h[17]:.0f}", flush=True)
         if h[0]:
             print(f"  [osd timers] shots={h[0]:.0f} chunks/shot={h[1] / h[0]:.2f} cols/shot={h[2] / h[0]:.1f} pivots/shot={h[3] / h[0]:.1f} kills/shot={h[5] / h[0]:.1f} "
-                  f"blocks/shot={h[6] / h[0]:.1f} kcycles/shot={h[4] / h[0] / 1e3:.1f} (sort {h[8] / h[0] / 1e3:.0f} columns+selectors {h[9] / h[0] / 1e3:.0f} chain||rows {h[10] / h[0] / 1e3:.0f} "
+                  f"blocks/shot={h[6] / h[0]:.1f} kcycles/shot={h[4] / h[0] / 1e3:.1f} (sort {h[14] / h[0] / 1e3:.0f} init {(h[8] - h[14]) / h[0] / 1e3:.0f} columns+selectors {h[9] / h[0] / 1e3:.0f} chain||rows {h[10] / h[0] / 1e3:.0f} "
                   f"last rows {h[11] / h[0] / 1e3:.0f} chunk tests {h[12] / h[0] / 1e3:.0f} chain {h[13] / h[0] / 1e3:.0f} collect {h[7] / h[0] / 1e3:.0f}; touched (row, operation) pairs per shot {h[15] / h[0]:.1f}; row updates of waves 0, 2, .. 14 without the barrier, kcycles: " + " ".join(f"{x / h[0] / 1e3:.0f}" for x in h[24:32]) + ")", flush=True)
             if a.counts_out:
                 import json
