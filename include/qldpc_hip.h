@@ -102,8 +102,8 @@ int qldpc_device_count(void);
  *   "mc_first_iteration"  reference-semantics Monte-Carlo plans: 1 (default) = bit-sliced first iteration (csrc/mc_first.hip) + the full decoder
  *                         on the shots it lists, 0 = the full decoder for every shot
  *   "mc_first_bits"       shots per lane of that kernel: 8 (default), 16, 32
- *   "osd_presort"         read at an OSD-0 launch: how many columns of the |llr| order the free-pivot OSD-0 kernels sort up front (default 1024; the rest is ordered
- *                         only when a sweep gets that far; 0 = everything up front)
+ *   "osd_presort"         read at an OSD-0 launch: how many columns of the |llr| order the free-pivot OSD-0 kernels sort up front (default -1 = automatic, about m; the rest is
+ *                         ordered only when a sweep gets that far; 0 = everything up front)
  *   "mc_tail_overlap"     read at plan creation: 1 (default) = whole batches on the plan's own streams so that the latency-bound pieces of one batch run
  *                         beside the next batch's first kernel (3 streams for large batches under reference semantics, 8 for batches <= 32768; fixed-work
  *                         plans with large batches keep the caller's stream), 2 = only OSD-0 + judge on a side stream, 0 = everything on the caller's stream

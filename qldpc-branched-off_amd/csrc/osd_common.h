@@ -156,8 +156,8 @@ __device__ __forceinline__ void osd_radix_sort(const double *__restrict__ llr, i
 }
 
 // The first columns of that order only.  The free-pivot kernels stop their sweep when the residual syndrome is gone (osd_gj.hip) -- on the circuit-level
-// matrices after ~170 of 8 800 columns -- so a full sort is mostly wasted: this one finds a key bound tau with `want` <= #{key <= tau} (a radix select:
-// 8-bit histograms from the top byte down, until the bin that holds the want-th key is small), splits the columns into S = {key <= tau} and the rest, both
+// matrices after ~170 of 8 800 columns -- so a full sort is mostly wasted: this one finds a key bound tau with `want` <= #{key <= tau} (from a sample of the keys,
+// checked by the count; a radix select when the sample falls short), splits the columns into S = {key <= tau} and the rest, both
 // in index order, and sorts S alone.  Returns Kt = |S|: ordw [0 .. Kt) is the head of the full order, ordw [Kt .. n) the other columns in INDEX order --
 // a caller that gets that far sorts them then (osd_sort_rest).  Scratch as for osd_radix_sort; cnt needs 256 * waves + waves + 8 words.
 __device__ __forceinline__ int osd_radix_sort_head(const double *__restrict__ llr, int n, int want, unsigned long long *keys, uint16_t *pa, uint16_t *pb,
@@ -166,69 +166,111 @@ __device__ __forceinline__ int osd_radix_sort_head(const double *__restrict__ ll
     const int NW = T >> 6, wv = tid >> 6, lane = tid & 63;
     if (want <= 0 || n <= 512 || n < 2 * want) { osd_radix_sort(llr, n, keys, pa, pb, cnt, ordw); return n; }
     for (int j = tid; j < n; j += T) keys[j] = osd_key(llr[j]);
-    unsigned *hist = cnt;                                                                   // [256]
-    unsigned *sel = cnt + 256;                                                              // [0] bin, [1] keys below the bin, [2] keys in it
-    unsigned long long prefix = 0ull;
-    int shift = 56, below = 0, Kt = n;
-    for (;; shift -= 8) {
-        if (tid < 256) hist[tid] = 0u;
-        __syncthreads();
-        for (int j0 = 0; j0 < n; j0 += T) {
-            // keys crowd into a few bins at the top levels (the exponent bytes): the lanes of a wave that share a digit add their count with ONE atomic
-            // (64 atomics on one LDS address take 64 passes of the pipe); what is left after four such groups goes lane by lane
-            const int j = j0 + tid;
-            const unsigned long long k = (j < n) ? keys[j] : 0ull;
-            const unsigned d = (unsigned)(k >> shift) & 255u;
-            bool take = (j < n) && (shift == 56 || (k >> (shift + 8)) == prefix);
-            unsigned long long active = __ballot(take);
-            for (int grp = 0; grp < 4 && active != 0ull; grp++) {
-                const int leader = __builtin_ctzll(active);
-                const unsigned dl = (unsigned)__builtin_amdgcn_readlane((int)d, leader);
-                const unsigned long long same = __ballot(take && d == dl);
-                if (lane == leader) atomicAdd(&hist[dl], (unsigned)__builtin_popcountll(same));
-                if (d == dl) take = false;
-                active &= ~same;
-            }
-            if (take) atomicAdd(&hist[d], 1u);
-        }
-        __syncthreads();
-        if (wv == 0) {                                                                      // lane: bins 4 lane .. 4 lane + 3
-            unsigned v[4], sum = 0u;
-#pragma unroll
-            for (int e = 0; e < 4; e++) { v[e] = hist[4 * lane + e]; sum += v[e]; }
-            unsigned inc = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o); if (lane >= o) inc += up; }
-            unsigned run = (unsigned)below + inc - sum;
-            int found = -1;
-            unsigned fbelow = 0u, fin = 0u;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if (found < 0 && run + v[e] >= (unsigned)want) { found = 4 * lane + e; fbelow = run; fin = v[e]; }
-                run += v[e];
-            }
-            const unsigned long long bal = __ballot(found >= 0);                            // (n >= want: some bin reaches it)
-            if (bal != 0ull && lane == __builtin_ctzll(bal)) { sel[0] = (unsigned)found; sel[1] = fbelow; sel[2] = fin; }
-        }
-        __syncthreads();
-        prefix = (prefix << 8) | (unsigned long long)sel[0];
-        below = (int)sel[1];
-        Kt = below + (int)sel[2];
-        __syncthreads();                                                                    // (hist / sel are rewritten by the next level)
-        if (Kt <= want + want / 2 || shift == 0) break;
-    }
-    // stable split: every wave owns a contiguous range of column indices
-    unsigned *wsum = cnt + 264;
+    // membership of the head: (key >> shift) <= prefix.  Every wave owns a contiguous range of column indices (the split below is stable).
+    unsigned *wsum = cnt + 264;                                                             // [waves] head members per wave
     const int span = (((n + NW - 1) / NW) + 63) & ~63;
     const int wbeg = min(n, wv * span), wend = min(n, wbeg + span);
-    int mine = 0;
-    for (int p0 = wbeg; p0 < wend; p0 += 64) {
-        const int j = p0 + lane;
-        const bool in = (j < wend) && (keys[j] >> shift) <= prefix;
-        mine += __builtin_popcountll(__ballot(in));
+    auto count_head = [&](int sh, unsigned long long pf) -> int {
+        int mine = 0;
+        for (int p0 = wbeg; p0 < wend; p0 += 64) {
+            const int j = p0 + lane;
+            mine += __builtin_popcountll(__ballot((j < wend) && (keys[j] >> sh) <= pf));
+        }
+        __syncthreads();                                                                    // (wsum may still be read from the previous count)
+        if (lane == 0) wsum[wv] = (unsigned)mine;
+        __syncthreads();
+        int tot = 0;
+        for (int w2 = 0; w2 < NW; w2++) tot += (int)wsum[w2];
+        return tot;
+    };
+    // (1) a key bound from a stratified sample of 256 keys: the sample key of rank ~1.15 * 256 * want / n (+ 4).  A per-key radix select costs 20 k cycles per
+    //     level of 8 bits -- more than sorting the head; the sample costs ~3 k, and the count that the split needs anyway tells whether it was large enough.
+    int shift = 0, Kt;
+    unsigned long long prefix;
+    {
+        unsigned long long *smp = reinterpret_cast<unsigned long long *>(cnt);             // [256] sample keys
+        unsigned *srank = cnt + 512;                                                        // [256]
+        unsigned long long *tau = reinterpret_cast<unsigned long long *>(cnt + 768);
+        __syncthreads();
+        if (tid < 256) {
+            const int stratum = n / 256;
+            smp[tid] = keys[(int)(((long long)tid * n) >> 8) + (int)(((unsigned)tid * 2654435761u >> 16) % (unsigned)stratum)];
+            srank[tid] = 0u;
+        }
+        __syncthreads();
+        const int parts = T >> 8, i = tid & 255, q = tid >> 8;                              // sample i against a share of the others (every lane another sample:
+        if (q < parts) {                                                                    //  the compared key is a broadcast read)
+            const unsigned long long ki = smp[i];
+            unsigned less = 0u;
+            for (int c = q * 256 / parts; c < (q + 1) * 256 / parts; c++) {
+                const unsigned long long kc = smp[c];
+                less += (kc < ki || (kc == ki && c < i)) ? 1u : 0u;
+            }
+            atomicAdd(&srank[i], less);
+        }
+        __syncthreads();
+        const unsigned rstar = min(254u, (unsigned)((256ll * want * 23 / 20 + n - 1) / n) + 4u);
+        if (tid < 256 && srank[tid] == rstar) *tau = smp[tid];
+        __syncthreads();
+        prefix = *tau;
+        Kt = count_head(0, prefix);
     }
-    if (lane == 0) wsum[wv] = (unsigned)mine;
-    __syncthreads();
+    // (2) the sample fell short (a few percent of the shots): the exact bound by a radix select -- 8-bit histograms from the top byte down, until the bin that
+    //     holds the want-th key is small
+    if (Kt < want) {
+        unsigned *hist = cnt;                                                               // [256]
+        unsigned *sel = cnt + 256;                                                          // [0] bin, [1] keys below the bin, [2] keys in it
+        int below = 0;
+        prefix = 0ull;
+        for (shift = 56;; shift -= 8) {
+            __syncthreads();
+            if (tid < 256) hist[tid] = 0u;
+            __syncthreads();
+            for (int j0 = 0; j0 < n; j0 += T) {
+                // keys crowd into a few bins at the top levels (the exponent bytes): the lanes of a wave that share a digit add their count with ONE atomic
+                // (64 atomics on one LDS address take 64 passes of the pipe); what is left after four such groups goes lane by lane
+                const int j = j0 + tid;
+                const unsigned long long k = (j < n) ? keys[j] : 0ull;
+                const unsigned d = (unsigned)(k >> shift) & 255u;
+                bool take = (j < n) && (shift == 56 || (k >> (shift + 8)) == prefix);
+                unsigned long long active = __ballot(take);
+                for (int grp = 0; grp < 4 && active != 0ull; grp++) {
+                    const int leader = __builtin_ctzll(active);
+                    const unsigned dl = (unsigned)__builtin_amdgcn_readlane((int)d, leader);
+                    const unsigned long long same = __ballot(take && d == dl);
+                    if (lane == leader) atomicAdd(&hist[dl], (unsigned)__builtin_popcountll(same));
+                    if (d == dl) take = false;
+                    active &= ~same;
+                }
+                if (take) atomicAdd(&hist[d], 1u);
+            }
+            __syncthreads();
+            if (wv == 0) {                                                                  // lane: bins 4 lane .. 4 lane + 3
+                unsigned v[4], sum = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { v[e] = hist[4 * lane + e]; sum += v[e]; }
+                unsigned inc = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+                unsigned run = (unsigned)below + inc - sum;
+                int found = -1;
+                unsigned fbelow = 0u, fin = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (found < 0 && run + v[e] >= (unsigned)want) { found = 4 * lane + e; fbelow = run; fin = v[e]; }
+                    run += v[e];
+                }
+                const unsigned long long bal = __ballot(found >= 0);                        // (n >= want: some bin reaches it)
+                if (bal != 0ull && lane == __builtin_ctzll(bal)) { sel[0] = (unsigned)found; sel[1] = fbelow; sel[2] = fin; }
+            }
+            __syncthreads();
+            prefix = (prefix << 8) | (unsigned long long)sel[0];
+            below = (int)sel[1];
+            if (below + (int)sel[2] <= want + want / 2 || shift == 0) break;
+        }
+        Kt = count_head(shift, prefix);
+    }
+    // (3) the stable split: head members to pa, the others to ordw [Kt ..), both in index order
     int baseS = 0;
     for (int w2 = 0; w2 < wv; w2++) baseS += (int)wsum[w2];
     int baseR = wbeg - baseS;

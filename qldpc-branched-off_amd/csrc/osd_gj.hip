@@ -486,7 +486,7 @@ int osd0_gj_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *d
     int rc = g->ws_misc.ensure(ord_bytes + (size_t)grid * P.sortws_words * 8);
     if (rc != QLDPC_OK) return rc;
     P.sortws = reinterpret_cast<unsigned long long *>(g->ws_misc.as<unsigned char>() + ord_bytes);
-    P.presort = osd_presort_choice();
+    P.presort = osd_presort_choice() < 0 ? (int)round_up(std::max(g->m, 1024), 1024) : osd_presort_choice();      // (automatic: about m columns, whole chunks)
     if ((rc = g->ws_redo.ensure((size_t)(max_listed + 4) * 4)) != QLDPC_OK) return rc;
     if ((rc = g->ws_queue.ensure(16)) != QLDPC_OK) return rc;
     P.ordws = g->ws_misc.as<uint16_t>();

@@ -92,11 +92,11 @@ __global__ __launch_bounds__(1024) void osd0_gjg_kernel(OsdGjgArgs PP) {
         const int8_t *hard = P.hard + shot * n, *synd = P.synd + shot * m;
         int8_t *sol = P.solution + shot * n;
         const long long t_start = OSD_CLOCK();
-        if (!P.ordering) {                                                   // column order: ascending |llr| (osd.py:11-12), ties by index
-            unsigned long long *keys = PP.ugkeys + (size_t)blockIdx.x * (size_t)(n + (n + 1) / 2);
-            uint16_t *pa = reinterpret_cast<uint16_t *>(keys + n), *pb = pa + n;
-            osd_radix_sort(llr, n, keys, pa, pb, reinterpret_cast<unsigned *>(lds + PP.offSort), ordw);
-        }
+        unsigned long long *skeys = PP.ugkeys + (size_t)blockIdx.x * (size_t)(n + (n + 1) / 2);       // sort scratch (global): keys, two index arrays
+        uint16_t *spa = reinterpret_cast<uint16_t *>(skeys + n), *spb = spa + n;
+        int sorted_upto = n;                                                 // ordw [0 .. sorted_upto) is in order, the rest in index order
+        if (!P.ordering)                                                     // column order: ascending |llr| (osd.py:11-12), ties by index -- its head (osd_common.h)
+            sorted_upto = osd_radix_sort_head(llr, n, P.presort, skeys, spa, spb, reinterpret_cast<unsigned *>(lds + PP.offSort), ordw);
         // ---- init: T = I, b = s + H hard (osd.py:8-9) ----
         for (size_t t = tid; t < (size_t)ms * mw; t += T) U[t] = 0ull;
         if (tid < 128) {                                                     // rows >= m never pivot
@@ -119,6 +119,10 @@ __global__ __launch_bounds__(1024) void osd0_gjg_kernel(OsdGjgArgs PP) {
         for (int base = 0; base < n && !finished; base += K) {
             const int L = min(K, n - base);
             d_chunks++;
+            if (base + L > sorted_upto) {                                    // past the sorted head: the other columns' order now
+                osd_sort_rest(llr, n, sorted_upto, skeys, spa, spb, reinterpret_cast<unsigned *>(lds + PP.offSort), ordw);
+                sorted_upto = n;
+            }
             for (int c = tid; c < L; c += T) {
                 sidx[c] = P.ordering ? (uint16_t)P.ordering[shot * n + base + c] : ordw[base + c];
                 alive[c] = 1;
@@ -333,6 +337,7 @@ int osd0_gjg_launch(const qldpc_graph *g, const int32_t *d_list, const int32_t *
     OsdGjArgs &P = PP.A;
     P = OsdGjArgs{};
     P.m = g->m; P.n = g->n; P.mw = (g->m + 63) / 64; P.K = 1024; P.cdeg = std::max(g->max_col_deg, 1);
+    P.presort = osd_presort_choice() < 0 ? (int)round_up(std::max(g->m, 1024), 1024) : osd_presort_choice();      // (automatic: about m columns, whole chunks)
     const size_t sort_cnt = (size_t)256 * 16 * 4 + 16 * 4 + 64;
     size_t off = 0;
     PP.offSort = (int)off; off += sort_cnt;

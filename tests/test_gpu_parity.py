@@ -159,7 +159,7 @@ def test_circuit_level_golden(Lb, golden, oracle, tag):
                     L.set_option("osd_presort", presort)
                     assert np.array_equal(L.osd0_batch(graph, g[f"{s}_syndromes"][case][None], g[f"{s}_llr"][case][None], g[f"{s}_err"][case][None])[0], sol2), (tag, s, t, presort)
             finally:
-                L.set_option("osd_presort", 1024)
+                L.set_option("osd_presort", -1)
             ref2 = oracle.osd0(ip, ix, n, g[f"{s}_syndromes"][case], g[f"{s}_llr"][case], g[f"{s}_err"][case])
             assert np.array_equal(sol2, ref2)
             assert np.array_equal(oracle.syndrome_check(ip, ix, sol2.astype(np.int8)), g[f"{s}_syndromes"][case])
@@ -181,7 +181,7 @@ def test_circuit_level_golden(Lb, golden, oracle, tag):
                 L.set_option("osd_presort", 1500)
                 assert np.array_equal(L.osd0_batch(graph, sy[None], ll[None], hd[None])[0], oracle.osd0(ip, ix, n, sy, ll, hd)), (tag, s, trial, "head 1500")
             finally:
-                L.set_option("osd_presort", 1024)
+                L.set_option("osd_presort", -1)
 
 
 @pytest.mark.parametrize("tag", ["circ72", "circ144"])
@@ -441,7 +441,7 @@ def test_code_capacity_small_pieces_many_failures_per_piece(L, oracle):
 def options(L):
     """qldpc_set_option switches are process-wide: put the defaults back after a test that turns them"""
     yield L.set_option
-    for name, v in (("mc_first_iteration", 1), ("mc_first_bits", 8), ("mc_tail_overlap", 1), ("osd_presort", 1024)):
+    for name, v in (("mc_first_iteration", 1), ("mc_first_bits", 8), ("mc_tail_overlap", 1), ("osd_presort", -1)):
         L.set_option(name, v)
 
 
@@ -1207,7 +1207,7 @@ def test_random_matrices_osd0_all_kernels(Lb, oracle, monkeypatch):
                     sol = L.osd0_batch(graph, synd, llr, hard, flags=env)
                     assert np.array_equal(sol, want), (gi, presort, env, np.flatnonzero((sol != want).any(1)))
         finally:
-            L.set_option("osd_presort", 1024)
+            L.set_option("osd_presort", -1)
 
 
 def _regular_graph(rng, m, cdeg, vdeg):
