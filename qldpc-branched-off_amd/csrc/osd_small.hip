@@ -105,7 +105,12 @@ __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
         // ---- Gauss-Jordan over the columns in reliability order ----
         int rank = 0;
         const int r0 = lane, r1 = lane + 64;
-        for (int c = 0; c < n && rank < P.rankH && rank < m; c++) {
+        // (the sweep also ends when no row at or below the diagonal holds a one of the reduced rhs: see the register kernel below)
+        auto residual_gone = [&]() -> bool {
+            return __ballot((r0 < m && r0 >= rank && (A[(size_t)r0 * rs + nw] & 1ull)) || (r1 < m && r1 >= rank && (A[(size_t)r1 * rs + nw] & 1ull))) == 0ull;
+        };
+        bool gone = residual_gone();
+        for (int c = 0; c < n && rank < P.rankH && rank < m && !gone; c++) {
             const int j = ord[c], w = j >> 6;
             const unsigned long long bit = 1ull << (j & 63);
             const bool c0 = (r0 < m) && (r0 >= rank) && (A[(size_t)r0 * rs + w] & bit) != 0ull;
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(64) void osd0_small_kernel(OsdSmallArgs P) {
             if (lane == 0) pivcol[rank] = (uint16_t)j;
             rank++;
             __builtin_amdgcn_wave_barrier();
+            gone = residual_gone();
         }
         // ---- back-fill (osd.py:19-25): e[pivot col] = reduced rhs at the pivot row; solution = (hard + e) % 2 ----
         if (P.jerr) for (int j = lane; j < n; j += 64) dsol[j] = (uint8_t)(hard[j] & 1);
@@ -219,7 +225,11 @@ __global__ __launch_bounds__(64) void osd0_small_reg_kernel(OsdSmallArgs P) {
         int pos0 = (r0 < m) ? r0 : 0x7fffffff, pos1 = (r1 < m) ? r1 : 0x7fffffff;            // current physical position of the lane's rows
         __builtin_amdgcn_wave_barrier();
         int rank = 0;
-        for (int c = 0; c < n && rank < P.rankH && rank < m; c++) {
+        // the sweep also ends when the residual syndrome is gone: no one of the reduced rhs in a row that has not pivoted (position >= rank).  A later pivot row
+        // then holds rhs = 0 -- its addition changes no rhs bit, the swap exchanges two zeros, its column gets e = 0: the answer is final (osd_gj.hip has the argument)
+        auto residual_gone = [&]() -> bool { return __ballot((pos0 >= rank && (a[0][NW] & 1ull)) || (pos1 >= rank && (a[1][NW] & 1ull))) == 0ull; };
+        bool gone = residual_gone();
+        for (int c = 0; c < n && rank < P.rankH && rank < m && !gone; c++) {
             const int j = ord[c], w = j >> 6;
             const unsigned long long bit = 1ull << (j & 63);
             unsigned long long x0 = a[0][0], x1 = a[1][0];
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(64) void osd0_small_reg_kernel(OsdSmallArgs P) {
             }
             if (lane == 0) pivcol[rank] = (uint16_t)j;
             rank++;
+            gone = residual_gone();
         }
         __builtin_amdgcn_wave_barrier();
         // back-fill (osd.py:19-25): e[pivot col] = reduced rhs of the row at the pivot's position; solution = (hard + e) % 2
