@@ -87,6 +87,10 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
         }
         if (tid == 0) { *sbar = 0; *tcnt = 0; }
         if (tid < 16) selb[tid] = 0u;
+        // the hard decision as LDS bytes (in the chunk's support table, idle until the first chunk): the row sums below gather ~35 of them per row
+        uint8_t *hstage = reinterpret_cast<uint8_t *>(colrows);
+        const bool staged = n <= K * cd * 2;
+        if (staged) for (int j = tid; j < n; j += T) hstage[j] = (uint8_t)hard[j];
         __syncthreads();
         for (int r = tid; r < m; r += T) {
             U[uix(r, r >> 6)] = 1ull << (r & 63);
@@ -98,10 +102,10 @@ __global__ __launch_bounds__(1024) void osd0_gj_kernel(OsdGjArgs P) {
 #pragma unroll
                     for (int j2 = 0; j2 < 8; j2++) cj[j2] = (k0 + j2 < deg) ? (int)P.ell_col[(size_t)(k0 + j2) * m + r] : -1;
 #pragma unroll
-                    for (int j2 = 0; j2 < 8; j2++) sy ^= (cj[j2] >= 0) ? (hard[cj[j2]] & 1) : 0;
+                    for (int j2 = 0; j2 < 8; j2++) sy ^= (cj[j2] >= 0) ? ((staged ? (int)hstage[cj[j2]] : (int)hard[cj[j2]]) & 1) : 0;
                 }
             } else {
-                for (int e = P.indptr[r]; e < P.indptr[r + 1]; e++) sy ^= hard[P.indices[e]] & 1;
+                for (int e = P.indptr[r]; e < P.indptr[r + 1]; e++) sy ^= (staged ? (int)hstage[P.indices[e]] : (int)hard[P.indices[e]]) & 1;
             }
             if (sy) atomicOr(&U[uix(brow, r >> 6)], 1ull << (r & 63));
         }
