@@ -155,6 +155,60 @@ __device__ __forceinline__ void osd_radix_sort(const double *__restrict__ llr, i
     osd_radix_passes<10>(keys, n, pa, pb, cnt, ordw);
 }
 
+// Order of a short list (len <= 2048 columns in pa, ascending column index) by value buckets: keys are non-negative doubles <= bound (finite).
+// Scratch: pb [len] bucket of an entry, pa [2048 .. 2048 + len) the columns in bucket order, cnt [0 .. 2048) cursors, cnt [2048 .. 4096) bucket starts, cnt [4096 ..) wave sums.
+// Returns false, with pa untouched, when a bucket holds more than 48 entries (a long run of equal keys, a lopsided distribution): the rank among bucket mates is
+// quadratic in the bucket, the caller's radix passes are not.
+__device__ __forceinline__ bool osd_bucket_order(const unsigned long long *keys, int len, double bound, uint16_t *pa, uint16_t *pb, unsigned *cnt, uint16_t *out) {
+    constexpr int NB = 2048;
+    const int tid = threadIdx.x, T = blockDim.x, NW = T >> 6, wv = tid >> 6, lane = tid & 63;
+    unsigned *cursor = cnt, *start = cnt + NB, *wsum = cnt + 2 * NB, *heavy = cnt + 2 * NB + 24;
+    uint16_t *byb = pa + 2048;
+    const double c = (bound > 0.0) ? (double)NB / bound : 0.0;
+    for (int e = tid; e < NB; e += T) cursor[e] = 0u;
+    if (tid == 0) *heavy = 0u;
+    __syncthreads();
+    for (int i = tid; i < len; i += T) {
+        const double x = __longlong_as_double((long long)keys[pa[i]]);
+        const int bk = min(NB - 1, (int)(x * c));
+        pb[i] = (uint16_t)bk;
+        atomicAdd(&cursor[bk], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan of the bucket counts: a contiguous share per thread, a wave scan of the shares, the waves' sums
+        const int per = (NB + T - 1) / T, b0 = min(NB, tid * per), b1 = min(NB, b0 + per);
+        unsigned sum = 0u, most = 0u;
+        for (int e = b0; e < b1; e++) { const unsigned v = cursor[e]; sum += v; most = max(most, v); }
+        if (most > 48u) *heavy = 1u;
+        unsigned inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        if (*heavy) { __syncthreads(); return false; }                                        // (uniform; the barrier keeps the flag from the next caller's reset)
+        unsigned run = inc - sum;
+        for (int w2 = 0; w2 < wv; w2++) run += wsum[w2];
+        for (int e = b0; e < b1; e++) { const unsigned v = cursor[e]; start[e] = run; cursor[e] = run; run += v; }
+    }
+    __syncthreads();
+    for (int i = tid; i < len; i += T) byb[atomicAdd(&cursor[pb[i]], 1u)] = pa[i];            // (columns, in any order inside a bucket)
+    __syncthreads();
+    for (int i = tid; i < len; i += T) {
+        const int bk = pb[i], j = pa[i];
+        const unsigned long long k = keys[j];
+        const int s0 = (int)start[bk], s1 = (bk + 1 < NB) ? (int)start[bk + 1] : len;
+        int rank = 0;
+        for (int q = s0; q < s1; q++) {
+            const int j2 = byb[q];
+            const unsigned long long k2 = keys[j2];
+            rank += (k2 < k || (k2 == k && j2 < j)) ? 1 : 0;
+        }
+        out[s0 + rank] = (uint16_t)j;
+    }
+    __syncthreads();
+    return true;
+}
+
 // The first columns of that order only.  The free-pivot kernels stop their sweep when the residual syndrome is gone (osd_gj.hip) -- on the circuit-level
 // matrices after ~170 of 8 800 columns -- so a full sort is mostly wasted: this one finds a key bound tau with `want` <= #{key <= tau} (from a sample of the keys,
 // checked by the count; a radix select when the sample falls short), splits the columns into S = {key <= tau} and the rest, both
@@ -285,6 +339,12 @@ __device__ __forceinline__ int osd_radix_sort_head(const double *__restrict__ ll
         baseR += __builtin_popcountll(rest);
     }
     __syncthreads();
+    // (4) the head in order.  Eight radix passes over ~1 300 keys cost 70 k cycles, nearly all of it fixed (a scan of 4 096 counters and five barriers per pass).
+    //     The head's keys are |llr| values between 0 and the bound: 2 048 buckets by VALUE (floor (key * 2048 / bound): monotone in the key, equal keys share a
+    //     bucket) hold 0.6 keys each, so bucket offsets + a rank among the bucket mates by (key, column) give the exact stable order in five barriers.
+    if (shift == 0 && Kt <= 2048 && n >= 2 * 2048 && prefix < 0x7FF0000000000000ull) {
+        if (osd_bucket_order(keys, Kt, __longlong_as_double((long long)prefix), pa, pb, cnt, ordw)) return Kt;
+    }
     if (Kt <= 2048) osd_radix_passes<2>(keys, Kt, pa, pb, cnt, ordw);
     else osd_radix_passes<10>(keys, Kt, pa, pb, cnt, ordw);
     return Kt;
