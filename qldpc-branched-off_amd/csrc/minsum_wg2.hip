@@ -31,11 +31,13 @@
 
 namespace qldpc {
 
-struct Wg2Chunk { double prior; int32_t deg, pure; };       // one per 64 column slots: pure = every slot exists and shares (deg, prior)
+struct Wg2Chunk { double prior; int32_t deg, pure; };       // one per 64 column slots: pure != 0: every slot exists and shares (deg, prior); pure >> 8 = chunks from here on (this one
+                                                            // included) that are pure with the same (deg, prior)
 
 struct Wg2Args {
     int m, n, nnz, max_iter, fixed, rdeg, cdeg, nan_deg1_only;
     int eoff[8];                   // EL[eoff[d] + c] = d-th edge (ascending check order) of column slot c, for the slots whose degree exceeds d (a prefix)
+    int wq[17];                    // variable pass: wave w takes the chunks wq[w] .. wq[w + 1] - 1 (contiguous, balanced by cost on the host)
     const int32_t *row_of_slot;    // [m]
     const uint8_t *degr;           // [m] degree of the row in slot s (descending)
     const uint16_t *ell_cs;        // [40][m] column SLOT of the k-th edge of row slot s (unused: 0)
@@ -164,12 +166,12 @@ __device__ __forceinline__ void wg2_row(const uint32_t (&idx)[4 * kWg2Chunks], c
 // the D edges of one column, every lane of the wave has exactly D: entries, then the three words of each check state, then the sum in
 // ascending check order (kernels.py:316).  ST64: the check states as 64-bit words, three per row slot (P1, P2, sign word).
 template <int D>
-__device__ __forceinline__ double wg2_col(uint32_t el_addr, const int (&eoff)[8], int c) {       // el_addr: LDS byte address of the edge list
+__device__ __forceinline__ double wg2_col(const uint32_t (&elb)[8], uint32_t c2) {       // elb [u]: LDS byte address of the rank-u segment of the edge list; c2 = 2 * column slot
     uint32_t e[D];
     double2 pp[D];
     unsigned long long si[D];
 #pragma unroll
-    for (int u = 0; u < D; u++) e[u] = wg2_lds_read_u16(el_addr + 2u * (uint32_t)(eoff[u] + c));
+    for (int u = 0; u < D; u++) e[u] = wg2_lds_read_u16(elb[u] + c2);                        // (one 2-cycle add per edge: the segment bases are scalars)
 #pragma unroll
     for (int u = 0; u < D; u++) {                                                            // row slot = e >> 6: byte offsets 16 * slot and 8 * slot
         const uint32_t a = (e[u] >> 2) & 0x3FF0u;
@@ -222,6 +224,9 @@ __global__ __launch_bounds__(1024) void minsum_wg2_kernel(Wg2Args A) {
     int eoff[8];
 #pragma unroll
     for (int d = 0; d < 8; d++) eoff[d] = A.eoff[d];
+    uint32_t elb[8];
+#pragma unroll
+    for (int d = 0; d < 8; d++) elb[d] = (uint32_t)A.offEL + 2u * (uint32_t)A.eoff[d];
     long long t_chk = 0, t_b1 = 0, t_frz = 0, t_var = 0, t_b2 = 0;                           // (diagnostic build only: OSD_CLOCK() is 0 otherwise)
     unsigned long long n_it = 0;
     (void)t_chk; (void)t_b1; (void)t_frz; (void)t_var; (void)t_b2; (void)n_it;
@@ -292,34 +297,45 @@ __global__ __launch_bounds__(1024) void minsum_wg2_kernel(Wg2Args A) {
             if (tid == 0) unsat[(it + 1) & 1] = 0;
             t_frz += OSD_CLOCK() - tq; tq = OSD_CLOCK(); n_it++;
             // variable pass: values_it
-            uint4 rec = reinterpret_cast<const uint4 *>(CH)[tid >> 6];                       // the wave's degree and prior of a pass: ONE broadcast read, a pass ahead
-            for (int c0 = tid & ~63; c0 < n; c0 += T) {
-                const int c = c0 + (tid & 63);
-                const uint4 cur = rec;
-                if (c0 + T < n) rec = reinterpret_cast<const uint4 *>(CH)[(c0 + T) >> 6];
-                struct { double prior; int deg; } ci;
-                ci.prior = __hiloint2double((int)cur.y, (int)cur.x); ci.deg = (int)cur.z;
-                if (__builtin_amdgcn_readfirstlane((int)cur.w)) {
-                    double s;
-                    const int dgu = __builtin_amdgcn_readfirstlane(ci.deg);
-                    switch (dgu) {
-                        case 0: s = 0.0; break;
-                        case 2: s = wg2_col<2>((uint32_t)A.offEL, eoff, c); break;
-                        case 3: s = wg2_col<3>((uint32_t)A.offEL, eoff, c); break;
-                        case 4: s = wg2_col<4>((uint32_t)A.offEL, eoff, c); break;
-                        case 5: s = wg2_col<5>((uint32_t)A.offEL, eoff, c); break;
-                        case 6: s = wg2_col<6>((uint32_t)A.offEL, eoff, c); break;
-                        default: {                                                           // degree 1, 7, 8
-                            s = 0.0;
-                            for (int d = 0; d < dgu; d++) s += wg2_edge(EL[eoff[d] + c]);
+            // Every wave owns a contiguous range of chunks (columns are sorted by (degree, prior), so a range is one to three RUNS of chunks of one class): the
+            // degree switch and the chunk record are per run, inside a run a pass is the edges, one add for the next chunk's addresses and the store.
+            {
+                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const int q1 = A.wq[wv + 1];
+                int q = A.wq[wv];
+                while (q < q1) {
+                    const uint4 cur = reinterpret_cast<const uint4 *>(CH)[q];                   // (a broadcast read)
+                    const int flag = __builtin_amdgcn_readfirstlane((int)cur.w);
+                    uint32_t c2 = 2u * (uint32_t)(64 * q + (tid & 63));
+                    if (flag) {
+                        const int qe = min(q1, q + (flag >> 8));
+                        const int dgu = __builtin_amdgcn_readfirstlane((int)cur.z);
+                        const double prior = __hiloint2double(__builtin_amdgcn_readfirstlane((int)cur.y), __builtin_amdgcn_readfirstlane((int)cur.x));
+#define QLDPC_WG2_RUN(D) for (; q < qe; q++, c2 += 128u) wg2_lds_write_f64(kWg2OffV + 4u * c2, wg2_col<D>(elb, c2) + prior);      /* kernels.py:320 */
+                        switch (dgu) {
+                            case 2: QLDPC_WG2_RUN(2) break;
+                            case 3: QLDPC_WG2_RUN(3) break;
+                            case 4: QLDPC_WG2_RUN(4) break;
+                            case 5: QLDPC_WG2_RUN(5) break;
+                            case 6: QLDPC_WG2_RUN(6) break;
+                            default:                                                         // degree 0, 1, 7, 8
+                                for (; q < qe; q++, c2 += 128u) {
+                                    double s = 0.0;
+                                    for (int d = 0; d < dgu; d++) s += wg2_edge(wg2_lds_read_u16(elb[d] + c2));
+                                    wg2_lds_write_f64(kWg2OffV + 4u * c2, s + prior);
+                                }
                         }
+#undef QLDPC_WG2_RUN
+                    } else {                                                                 // a chunk that mixes classes (or the ragged last one): per-lane degree and prior
+                        const int c = (int)(c2 >> 1);
+                        if (c < n) {
+                            const int dj = A.degc[c];
+                            double s = 0.0;
+                            for (int d = 0; d < dj; d++) s += wg2_edge(EL[eoff[d] + c]);
+                            V[c] = s + A.prior_s[c];
+                        }
+                        q++;
                     }
-                    wg2_lds_write_f64(kWg2OffV + 8u * (uint32_t)c, s + ci.prior);            // kernels.py:320
-                } else if (c < n) {                                                          // a chunk that mixes classes (or the ragged last one): per-lane degree and prior
-                    const int dj = A.degc[c];
-                    double s = 0.0;
-                    for (int d = 0; d < dj; d++) s += wg2_edge(EL[eoff[d] + c]);
-                    V[c] = s + A.prior_s[c];
                 }
             }
             t_var += OSD_CLOCK() - tq; tq = OSD_CLOCK();
@@ -344,6 +360,7 @@ struct Wg2Prep {
     bool usable = false;
     int nan_deg1_only = 1, has_deg1 = 0;
     int eoff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int wq[17] = {0};
     size_t lds = 0;
     int offEL = 0, offF = 0, offCH = 0;
     DevBuf row_of_slot, degr, ell_cs, el, chunks, prior_s, degc, slot_of_col;
@@ -400,6 +417,28 @@ static int wg2_build(const qldpc_graph *g, const double *prior, Wg2Prep &P) {
         mixed += pure ? 0 : 1;
     }
     if (4 * mixed > nch + 3) return QLDPC_OK;                       // priors too diverse for class scalars: the table kernel serves this input
+    for (int q = nch - 1; q >= 0; q--) {                            // run lengths: chunks from q on that are pure with the class of q
+        if (!chunks[q].pure) continue;
+        int run = 1;
+        if (q + 1 < nch && chunks[q + 1].pure && chunks[q + 1].deg == chunks[q].deg && std::memcmp(&chunks[q + 1].prior, &chunks[q].prior, 8) == 0) run += chunks[q + 1].pure >> 8;
+        chunks[q].pure = 1 | (run << 8);
+    }
+    {   // contiguous chunk ranges of the 16 waves, balanced by cost (a pass: ~36 instruction slots + ~13 per edge; a mixed chunk runs the per-lane form)
+        std::vector<int> cost(nch);
+        long long total = 0;
+        // (measured on the circuit-level matrices: 10 .. 60 per pass and 10 .. 20 per edge all land within 4 % of each other -- 139 chunks over 16 waves leave
+        //  a granularity of half a chunk whatever the model; edges alone, without the per-pass term, cost 15 %)
+        for (int q = 0; q < nch; q++) { cost[q] = chunks[q].pure ? 36 + 13 * chunks[q].deg : 60 + 20 * g->max_col_deg; total += cost[q]; }
+        long long acc = 0;
+        int q = 0;
+        P.wq[0] = 0;
+        for (int w = 0; w < 16; w++) {
+            const long long goal = total * (w + 1) / 16;
+            while (q < nch && (acc + cost[q] / 2 <= goal || w == 15)) { acc += cost[q]; q++; }
+            P.wq[w + 1] = q;
+        }
+        P.wq[16] = nch;
+    }
     std::vector<uint8_t> degr(m), degc(n);
     for (int s = 0; s < m; s++) degr[s] = (uint8_t)rdeg(ros[s]);
     for (int c = 0; c < n; c++) degc[c] = (uint8_t)cdeg(cos[c]);
@@ -466,6 +505,7 @@ int minsum_wg2_launch(const qldpc_graph *g, const Wg2Prep *P, int64_t B, const i
     A.m = g->m; A.n = g->n; A.nnz = g->nnz; A.max_iter = max_iter; A.fixed = (flags & QLDPC_FLAG_FIXED_ITERS) ? 1 : 0;
     A.rdeg = g->max_row_deg; A.cdeg = g->max_col_deg; A.nan_deg1_only = P->nan_deg1_only;
     for (int d = 0; d < 8; d++) A.eoff[d] = P->eoff[d];
+    for (int w = 0; w <= 16; w++) A.wq[w] = P->wq[w];
     A.row_of_slot = P->row_of_slot.as<int32_t>(); A.degr = P->degr.as<uint8_t>(); A.ell_cs = P->ell_cs.as<uint16_t>(); A.el = P->el.as<uint16_t>();
     A.chunks = P->chunks.as<Wg2Chunk>(); A.prior_s = P->prior_s.as<double>(); A.degc = P->degc.as<uint8_t>(); A.slot_of_col = P->slot_of_col.as<int32_t>();
     A.B = B; A.synd = d_synd; A.alpha = d_alpha; A.clip = clip;

@@ -161,7 +161,7 @@ __device__ __forceinline__ void osd_radix_sort(const double *__restrict__ llr, i
 // quadratic in the bucket, the caller's radix passes are not.
 __device__ __forceinline__ bool osd_bucket_order(const unsigned long long *keys, int len, double bound, uint16_t *pa, uint16_t *pb, unsigned *cnt, uint16_t *out) {
     constexpr int NB = 2048;
-    const int tid = threadIdx.x, T = blockDim.x, NW = T >> 6, wv = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, T = blockDim.x, wv = tid >> 6, lane = tid & 63;
     unsigned *cursor = cnt, *start = cnt + NB, *wsum = cnt + 2 * NB, *heavy = cnt + 2 * NB + 24;
     uint16_t *byb = pa + 2048;
     const double c = (bound > 0.0) ? (double)NB / bound : 0.0;
