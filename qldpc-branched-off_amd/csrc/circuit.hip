@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void circuit_sample_kernel(int64_t B, int64_t 
 // per trial (32 lanes): decoded logical action H_logical @ det (engine.py:99,119) vs the true logical flips, both sectors
 struct JudgeSector {
     int m, n;
-    const int32_t *indptr, *indices;
+    const int32_t *indptr, *indices, *colptr, *rowidx;
     const uint64_t *logmask;
     const int8_t *synd, *det;
     const uint8_t *conv;
@@ -142,9 +142,53 @@ __device__ __forceinline__ void judge_sector(const JudgeSector &S, int64_t b, in
     bad = bd != 0;
 }
 
+// The same verdicts from the ONES of the correction: a decoded error has ~100 ones among ~8 800 columns, so H @ det is ~600 parity flips (the columns' rows, CSC) into a bit
+// set of the trial in LDS instead of the ~31 000 byte gathers per sector of the row-wise form above (1.15 ms per 16 384-trial batch of config 5); the scan of det -- aligned
+// dwords, the ragged head and tail as bytes -- is what is left.  `par`: m bits of LDS owned by the trial's 32 lanes.
+__device__ __forceinline__ void judge_sector_sparse(const JudgeSector &S, int64_t b, int lane, uint32_t *par, bool &err, bool &nz, bool &bad) {
+    const uint8_t *d = reinterpret_cast<const uint8_t *>(S.det) + b * S.n;
+    const int8_t *s = S.synd + b * S.m;
+    const int mwords = (S.m + 31) >> 5;
+    for (int w = lane; w < mwords; w += 32) par[w] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    uint64_t lm = 0;
+    auto one = [&](int j) {
+        lm ^= S.logmask[j];
+        for (int e = S.colptr[j]; e < S.colptr[j + 1]; e++) { const int r = S.rowidx[e]; atomicXor(&par[r >> 5], 1u << (r & 31)); }
+    };
+    const int head = (int)((4 - (reinterpret_cast<uintptr_t>(d) & 3)) & 3), nhead = head < S.n ? head : S.n;
+    if (lane < nhead && (d[lane] & 1)) one(lane);
+    const int nw = (S.n - nhead) >> 2;
+    const uint32_t *dw = reinterpret_cast<const uint32_t *>(d + nhead);
+    for (int w = lane; w < nw; w += 32) {
+        uint32_t x = dw[w] & 0x01010101u;
+        while (x) {                                                        // (rare: a correction is sparse)
+            const int byte = (__builtin_ctz(x)) >> 3;
+            x &= x - 1u;
+            one(nhead + 4 * w + byte);
+        }
+    }
+    const int tail0 = nhead + 4 * nw;
+    if (tail0 + lane < S.n && (d[tail0 + lane] & 1)) one(tail0 + lane);
+    __builtin_amdgcn_wave_barrier();
+    int bd = 0, z = 0;
+    for (int i = lane; i < S.m; i += 32) {
+        const int si = s[i] & 1;
+        bd |= (int)((par[i >> 5] >> (i & 31)) & 1u) ^ si;
+        z |= si;
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) { lm ^= __shfl_xor(lm, off, 32); bd |= __shfl_xor(bd, off, 32); z |= __shfl_xor(z, off, 32); }
+    err = (lm != S.true_log[b]);
+    nz = z != 0;
+    bad = bd != 0;
+}
+
+template <bool SPARSE>
 __global__ __launch_bounds__(256) void circuit_judge_kernel(int64_t B, JudgeSector Z, JudgeSector X, unsigned long long *__restrict__ tally,
                                                             uint8_t *__restrict__ outcome, const int32_t *__restrict__ fail_counts) {
     __shared__ unsigned long long acc[QLDPC_TALLY_SLOTS];
+    __shared__ uint32_t parbits[SPARSE ? 8 * 2 * 128 : 1];                      // per trial of the workgroup: the two sectors' parity bits (m <= 4096)
     if (threadIdx.x < QLDPC_TALLY_SLOTS) acc[threadIdx.x] = 0ull;
     __syncthreads();
     if (fail_counts && blockIdx.x == 0 && threadIdx.x == 0) {                 // OSD-0 calls of this batch = its BP failures per sector
@@ -156,8 +200,14 @@ __global__ __launch_bounds__(256) void circuit_judge_kernel(int64_t B, JudgeSect
     const int64_t b = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
     if (b < B) {
         bool ze, zn, zb, xe, xn, xb;
-        judge_sector(Z, b, lane, ze, zn, zb);
-        judge_sector(X, b, lane, xe, xn, xb);
+        if (SPARSE) {
+            uint32_t *par = parbits + (threadIdx.x >> 5) * 256;
+            judge_sector_sparse(Z, b, lane, par, ze, zn, zb);
+            judge_sector_sparse(X, b, lane, par + 128, xe, xn, xb);
+        } else {
+            judge_sector(Z, b, lane, ze, zn, zb);
+            judge_sector(X, b, lane, xe, xn, xb);
+        }
         if (lane == 0) {
             if (outcome) outcome[b] = (uint8_t)((ze ? 1 : 0) | (xe ? 2 : 0));               // (z_err, x_err) of engine.py:117-122
             atomicAdd(&acc[QLDPC_TALLY_TRIALS], 1ull);
@@ -513,12 +563,16 @@ static int circuit_run(qldpc_circuit_plan *P, uint64_t seed, int64_t trial_begin
             QLDPC_HIP_TRY(hipStreamWaitEvent(s, P->ev_x_done, 0));
         }
         if ((rc = phase_mark(P, QLDPC_PHASE_JUDGE, s, true)) != QLDPC_OK) return rc;
-        JudgeSector Z{P->gz->m, P->gz->n, P->gz->d_indptr, P->gz->d_indices, P->d_lm_z.as<uint64_t>(), P->d_syn_z.as<int8_t>(), P->d_det_z.as<int8_t>(),
+        JudgeSector Z{P->gz->m, P->gz->n, P->gz->d_indptr, P->gz->d_indices, P->gz->d_colptr, P->gz->d_rowidx, P->d_lm_z.as<uint64_t>(), P->d_syn_z.as<int8_t>(), P->d_det_z.as<int8_t>(),
                       P->d_conv_z.as<uint8_t>(), P->d_iter_z.as<int32_t>(), P->d_true_z.as<unsigned long long>()};
-        JudgeSector X{P->gx->m, P->gx->n, P->gx->d_indptr, P->gx->d_indices, P->d_lm_x.as<uint64_t>(), P->d_syn_x.as<int8_t>(), P->d_det_x.as<int8_t>(),
+        JudgeSector X{P->gx->m, P->gx->n, P->gx->d_indptr, P->gx->d_indices, P->gx->d_colptr, P->gx->d_rowidx, P->d_lm_x.as<uint64_t>(), P->d_syn_x.as<int8_t>(), P->d_det_x.as<int8_t>(),
                       P->d_conv_x.as<uint8_t>(), P->d_iter_x.as<int32_t>(), P->d_true_x.as<unsigned long long>()};
-        hipLaunchKernelGGL(circuit_judge_kernel, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, B, Z, X, P->d_tally.as<unsigned long long>(),
-                           outcome ? P->d_outcome.as<uint8_t>() : (uint8_t *)nullptr, P->use_osd ? P->d_count.as<int32_t>() : (const int32_t *)nullptr);
+        if (P->gz->m <= 4096 && P->gx->m <= 4096 && P->gz->d_colptr && P->gx->d_colptr)
+            hipLaunchKernelGGL(circuit_judge_kernel<true>, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, B, Z, X, P->d_tally.as<unsigned long long>(),
+                               outcome ? P->d_outcome.as<uint8_t>() : (uint8_t *)nullptr, P->use_osd ? P->d_count.as<int32_t>() : (const int32_t *)nullptr);
+        else
+            hipLaunchKernelGGL(circuit_judge_kernel<false>, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, s, B, Z, X, P->d_tally.as<unsigned long long>(),
+                               outcome ? P->d_outcome.as<uint8_t>() : (uint8_t *)nullptr, P->use_osd ? P->d_count.as<int32_t>() : (const int32_t *)nullptr);
         QLDPC_HIP_TRY(hipGetLastError());
         if ((rc = phase_mark(P, QLDPC_PHASE_JUDGE, s, false)) != QLDPC_OK) return rc;
         P->batches++;           // (the next batch's sampler follows the judge on s, which already waited for sector X)
