@@ -600,6 +600,14 @@ def test_circuit_level_tally_matches_oracle(L, oracle, golden, tag, ntrial):
     assert np.array_equal(t, ref), (t.tolist(), ref.tolist())
     assert ref[L.TALLY["osd_z"]] > 0 and ref[L.TALLY["unsat_z"]] == 0 and ref[L.TALLY["total_err"]] > 0
     plan.close()
+    # without OSD-0 the BP failures are judged as they are: the judge's syndrome check (H @ det, from the ones of the correction) has something to find
+    ref0 = oracle.circuit_sample_decode_tally(circ, secs[0], secs[1], p, 77, 0, ntrial, max_iter=50, use_osd=False, threads=0)
+    plan0 = L.CircuitPlan(g, g["Lx"], g["Lz"], graphs[0], graphs[1], priors[0], priors[1], masks[0], masks[1], p, max_iter=50, use_osd=False, batch=64)
+    plan0.run(77, 0, ntrial)
+    t0 = plan0.read()
+    plan0.close()
+    assert np.array_equal(t0, ref0), (t0.tolist(), ref0.tolist())
+    assert ref0[L.TALLY["unsat_z"]] > 0 and ref0[L.TALLY["unsat_x"]] > 0
 
 
 def _two_alpha_tally(oracle, circ, secs, seed, count, max_iter, mode, alpha_z, alpha_x):
