@@ -130,7 +130,7 @@ def lib():
                                      "or __graft_entry__.build()); there is no CPU fallback")
                 # Code-capacity plans keep up to eight small pieces in flight on streams of their own; the HIP runtime multiplexes streams onto
                 # GPU_MAX_HW_QUEUES hardware queues (default 4), which is what bounds them: [[72,12,6]] at batch 4096 runs 1.0e8 shots/s on 4 queues,
-                # 1.4e8 on 16 (profiles/r04e_other_configs.txt).  Read when the HIP runtime initialises, so it only takes effect if nothing in this process
+                # 1.4e8 on 16 (profiles/r04f_other_configs.txt).  Read when the HIP runtime initialises, so it only takes effect if nothing in this process
                 # has touched the GPU yet; a value the caller exported wins.
                 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
                 L = C.CDLL(SO_PATH)

@@ -3,7 +3,7 @@
 #   bash tools/profile_round.sh r04a          ->  gpurun_out/<tag>/ : bench JSON (plain and under rocprofv3), kernel stats CSV, PMC passes,
 #                                                  pmc.json + <tag>_pmc.txt, OSD workload counts (diagnostic build), issue-rate table
 # Copy what is to be judged into profiles/ afterwards (tools/cp them by hand: see profiles/README.md).
-TAG=${1:-r04e}
+TAG=${1:-r04f}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT/pmc"
 export TMPDIR=/tmp
