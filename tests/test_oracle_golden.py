@@ -275,3 +275,69 @@ def test_gf2_elimination_production_size(oracle, golden):
     P, b, pr, pc = oracle.gf2_elimination_packed(H[:, g["ordering"].astype(np.int64)], g["b"])
     assert np.array_equal(pr, g["pivot_rows"]) and np.array_equal(pc, g["pivot_cols"]) and np.array_equal(b, g["b_red"])
     assert np.array_equal(P, g["A_packed_red"])
+
+
+def _osd0_truncated(H, s, llr, hard, order):
+    """OSD-0 (osd.py:5-29 with the first-row pivot rule of kernels.py:66-92) that ENDS its sweep as soon as the reduced right-hand side has no one left at or
+    below the diagonal -- the shortcut the HIP kernels take.  Returns (solution, columns swept, pivots, whether the sweep ended on the test)."""
+    m, n = H.shape
+    A = H[:, order].astype(np.uint8) % 2
+    b = (s.astype(np.int64) + H.astype(np.int64) @ hard.astype(np.int64)) % 2
+    b = b.astype(np.uint8)
+    rank, pivcols, stopped, swept = 0, [], False, 0
+    for c in range(n):
+        if not b[rank:].any():
+            stopped = True
+            break
+        if rank >= m:
+            break
+        swept = c + 1
+        rows = np.flatnonzero(A[rank:, c]) + rank
+        if rows.size == 0:
+            continue
+        p = rows[0]
+        if p != rank:
+            A[[p, rank]] = A[[rank, p]]
+            b[[p, rank]] = b[[rank, p]]
+        for r in np.flatnonzero(A[:, c]):
+            if r != rank:
+                A[r] ^= A[rank]
+                b[r] ^= b[rank]
+        pivcols.append(c)
+        rank += 1
+    stopped = stopped or not b[rank:].any()                      # (gone with the last column swept)
+    e = np.zeros(n, np.uint8)
+    for t, c in enumerate(pivcols):
+        e[order[c]] = b[t]
+    return ((hard.astype(np.uint8) + e) % 2).astype(np.int8), swept, rank, stopped
+
+
+def test_osd0_sweep_may_end_when_the_residual_is_gone(oracle):
+    """The identity behind the round-4 OSD-0 kernels, checked on the CPU against the literal port of the reference: once no row at or below the diagonal holds a
+    one of the reduced right-hand side, the rest of the sweep changes nothing -- for a realisable syndrome the truncated sweep gives the reference's solution
+    (usually after a fraction of the columns); for a syndrome outside the column space the test never fires and the sweep runs to its end."""
+    rng = np.random.default_rng(20261005)
+    fired = early = 0
+    for trial in range(300):
+        m, n = int(rng.integers(3, 24)), int(rng.integers(4, 60))
+        H = (rng.random((m, n)) < rng.choice([0.08, 0.2, 0.45])).astype(np.int8)
+        if m > 4 and trial % 3 == 0:
+            H[2] = H[0] ^ H[1]                                   # dependent rows
+        ip = np.concatenate([[0], np.cumsum(H.sum(1))]).astype(np.int32)
+        ix = np.concatenate([np.flatnonzero(r) for r in H]).astype(np.int32) if H.any() else np.zeros(0, np.int32)
+        llr = np.round(rng.normal(0, 2, n), int(rng.integers(0, 3)))             # ties
+        hard = (rng.random(n) < 0.15).astype(np.int8)
+        order = np.argsort(np.abs(llr), kind="stable")
+        consistent = trial % 4 != 0
+        s = (H.astype(np.int64) @ (rng.random(n) < 0.2).astype(np.int64) % 2).astype(np.int8) if consistent else (rng.random(m) < 0.5).astype(np.int8)
+        ref = oracle.osd0(ip, ix, n, s, llr, hard)
+        sol, swept, rank, stopped = _osd0_truncated(H, s, llr, hard, order)
+        realisable = np.array_equal((H.astype(np.int64) @ ref.astype(np.int64)) % 2, s % 2)
+        if realisable:
+            assert stopped and np.array_equal(sol, ref), (trial, m, n)
+            fired += 1
+            early += swept < n
+        else:
+            assert not stopped, (trial, m, n)                    # a one in an unused row survives to the end
+            assert np.array_equal(sol, ref), (trial, m, n)       # (the full sweep, literally)
+    assert fired > 150 and early > 100
