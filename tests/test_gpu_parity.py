@@ -574,6 +574,39 @@ def _circuit_setup(L, oracle, tag, golden):
     return g, circ, secs, graphs, priors, masks
 
 
+def test_osd0_key_distributions_at_production_size(L, oracle):
+    """The device's own |llr| order at 1008 x 8785 on key distributions chosen against the sorted head (sample-based bound, split, value buckets, the rest on demand):
+    every key equal; two values; a distinct head below a 3000-long run of equal keys; a run of equal keys that STRADDLES the bound; nearly everything infinite;
+    keys descending with the column index; a head squeezed against the bound (lopsided buckets).  Realisable and unrealisable syndromes; against the oracle."""
+    from qldpc_amd.data import load_circuit_matrices
+    d = load_circuit_matrices("circ144")
+    rng = np.random.default_rng(7)
+    for s in "ZX":
+        ip, ix = d[f"Hdec{s}_indptr"], d[f"Hdec{s}_indices"]
+        m, n = (int(v) for v in d[f"Hdec{s}_shape"])
+        graph = L.Graph(ip, ix, n)
+        cases = []
+        cases.append(np.full(n, 2.5))
+        two = np.where(rng.random(n) < 0.1, 0.75, 6.0); cases.append(two)
+        a = np.full(n, 9.0); idx = rng.permutation(n); a[idx[:1300]] = rng.random(1300) * 3.0; a[idx[4300:]] = 9.0 + rng.random(n - 4300) * 5.0; cases.append(a)
+        b = 20.0 + rng.random(n) * 5.0; idx = rng.permutation(n); b[idx[:600]] = rng.random(600); b[idx[600:2600]] = 4.0; cases.append(b)
+        c = np.full(n, np.inf); c[rng.permutation(n)[:100]] = rng.random(100) * 7.0; cases.append(c)
+        cases.append(np.arange(n, 0, -1) * 1e-3)
+        e = 10.0 - rng.random(n) ** 8 * 1e-6; e[rng.permutation(n)[:50]] = rng.random(50); cases.append(e)
+        llr = np.stack(cases) * np.where(rng.random((len(cases), n)) < 0.5, -1.0, 1.0)
+        B = llr.shape[0]
+        err = (rng.random((B, n)) < 0.01).astype(np.int8)
+        synd = np.stack([oracle.syndrome_check(ip, ix, e_) for e_ in err])
+        hard = (rng.random((B, n)) < 0.002).astype(np.int8)
+        for unreal in (False, True):
+            sy = synd.copy()
+            if unreal:
+                sy[:, :7] ^= 1
+            want = np.stack([oracle.osd0(ip, ix, n, sy[i], llr[i], hard[i]) for i in range(B)])
+            got = L.osd0_batch(graph, sy, llr, hard)
+            assert np.array_equal(got, want), (s, unreal, np.flatnonzero((got != want).any(1)))
+
+
 @pytest.mark.parametrize("tag,ntrial", [("circ72", 96), ("circ144", 24)])
 def test_circuit_sampler_equals_literal_simulation(L, oracle, golden, tag, ntrial):
     """Signature-XOR sampler on the GPU == the oracle's literal noisy-circuit simulation on the same Philox draws (a10-a13)."""
